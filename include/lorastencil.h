@@ -1,0 +1,195 @@
+/*
+ * lorastencil.h -- C ABI of the MI355X-native low-rank stencil engine (liblorastencil_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of zondie17/LoRAStencil: the stencil sweep and
+ * its time-step driver behind `lorastencil_{1d,2d,3d} shape input_size time_size`.  Plain C,
+ * plain pointers and sizes, no C++/torch types.  Every entry point names the reference
+ * interface it replaces (file:line under /root/reference/src/).
+ *
+ * Three groups:
+ *   A. host-buffer operators  -- one-to-one replacements of the reference's seven gpu_*()
+ *      functions (same argument meaning, padded host arrays in and out, same stdout lines);
+ *   B. device-resident plans  -- the same sweep on caller-owned device buffers and a caller
+ *      stream (what bench.py, the multi-GPU slab driver and the CLIs are built on);
+ *   C. host helpers on the path -- params tables, the low-rank factor precompute, the
+ *      glibc-rand() fill of the reference harness.
+ *
+ * Error model: every function returns LORA_OK (0) or a negative LORA_E* code and never exits
+ * the process (the reference prints and exit(1)/abort()s: 2d_utils.h:6-36).  The C++ shims in
+ * lorastencil_ref_shims.h restore the reference's print-and-exit behaviour on top of this.
+ */
+#ifndef LORASTENCIL_H
+#define LORASTENCIL_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LORA_VERSION 100
+
+/* ---- status codes ---------------------------------------------------------------------- */
+#define LORA_OK 0
+#define LORA_EINVAL (-1)       /* bad shape / null pointer / negative size               */
+#define LORA_EUNSUPPORTED (-2) /* size the kernels cannot take (e.g. odd innermost extent) */
+#define LORA_EHIP (-3)         /* a HIP runtime call failed (see lora_last_error())        */
+#define LORA_ENOMEM (-4)
+#define LORA_ENODEVICE (-5) /* no HIP device visible: the engine has NO CPU fallback     */
+
+/* ---- shapes: the CLI `shape` argument (README.md:37-48) ---------------------------------- */
+typedef enum lora_shape {
+    LORA_1D1R = 0,     /* 1d_utils.h:38-42 star_1d1r */
+    LORA_1D2R = 1,     /* star_1d2r */
+    LORA_STAR2D1R = 2, /* 2d_utils.h:38-44 star_2d1r */
+    LORA_BOX2D1R = 3,  /* box_2d1r (served by the box2d3r operator, 2d/main.cu:276-279) */
+    LORA_STAR2D3R = 4, /* star_2d3r */
+    LORA_BOX2D3R = 5,  /* box_2d3r */
+    LORA_STAR3D1R = 6, /* 3d_utils.h:39-42 star_3d1r */
+    LORA_BOX3D1R = 7,  /* box_3d1r */
+    LORA_NUM_SHAPES = 8
+} lora_shape;
+
+typedef enum lora_dtype {
+    LORA_F64 = 0 /* the reference's only type (DATA_TYPE double, 2d_utils.h:1) */
+} lora_dtype;
+
+/* Kernel formulation of one sweep (B: lora_plan_set_variant). */
+typedef enum lora_variant {
+    LORA_VARIANT_AUTO = 0,   /* what the roofline evidence in DESIGN.md picked per shape           */
+    LORA_VARIANT_DIRECT = 1, /* LDS-tiled direct taps on the fp64 vector FMA pipe                  */
+    LORA_VARIANT_MFMA = 2    /* low-rank (U X) V products on v_mfma_f64_16x16x4 (2D shapes only)   */
+} lora_variant;
+
+/* Number of taps in `params` / weights for a shape: 9 (1D), 49 (2D), 27 (3D). */
+int lora_shape_ntaps(int shape);
+/* Number of interior dimensions of a shape (1, 2 or 3), 0 for an unknown shape. */
+int lora_shape_ndim(int shape);
+/* Parse the CLI spelling ("star2d1r", ...) -> shape id, or LORA_EINVAL. */
+int lora_shape_from_name(const char *name);
+/* The spelling the reference prints in its INFO line ("star_2d1r", 2d/main.cu:5-10). */
+const char *lora_shape_info_name(int shape);
+/* Padded element count: 1D n+8; 2D (m+8)(n+8); 3D (h+2)(m+4)(n+8) (2d/main.cu:217-221). */
+size_t lora_padded_count(int shape, const int *dims);
+/* GStencil/s accounting factor F the reference multiplies by. */
+int lora_shape_gstencil_factor(int shape);
+
+const char *lora_strerror(int status);
+/* Text of the last HIP failure on this thread ("" if none). */
+const char *lora_last_error(void);
+/* Number of visible HIP devices (0 if none; never fails). */
+int lora_device_count(void);
+
+/* ========================================================================================
+ * A. Host-buffer operators: drop-in for the reference's gpu_*().
+ *
+ *   in, out : caller-owned PADDED host arrays (1D n+8; 2D (m+8)(n+8); 3D (h+2)(m+4)(n+8)),
+ *             row-major; the whole padded `in` is read (halo values matter), the whole padded
+ *             `out` is written (1D: all but the last element, 1d/gpu_1r.cu:134).
+ *   params  : 9 / 49 / 27 doubles, row-major, centre at 4 / 24 / 13.  Honoured exactly as far as
+ *             the reference honours them (ignored by star2d1r and star3d1r; box3d1r reads
+ *             params[0..2]; box2d goes through the pyramid factoriser).
+ *   times   : number of kernel applications; result = ping-pong buffer [times % 2].
+ *   Side effect: prints the reference's three stdout lines (label, Time, GStencil/s).
+ *   Device memory is allocated and freed inside the call.
+ * ====================================================================================== */
+int lora_gpu_1d1r(const double *in, double *out, const double *params, int times, int input_n);      /* gpu_1d1r      1d_utils.h:45, 1d/gpu_1r.cu:90   */
+int lora_gpu_1d2r(const double *in, double *out, const double *params, int times, int input_n);      /* gpu_1d2r      1d_utils.h:47, 1d/gpu_2r.cu:91   */
+int lora_gpu_star_2d1r(const double *in, double *out, const double *params, int times, int input_m,
+                       int input_n);                                                                 /* gpu_star_2d1r 2d_utils.h:47, 2d/gpu.cu:484     */
+int lora_gpu_star_2d3r(const double *in, double *out, const double *params, int times, int input_m,
+                       int input_n);                                                                 /* gpu_star_2d3r 2d_utils.h:49, 2d/gpu.cu:426     */
+int lora_gpu_box_2d3r(const double *in, double *out, const double *params, int times, int input_m,
+                      int input_n);                                                                  /* gpu_box_2d3r  2d_utils.h:51, 2d/gpu.cu:276     */
+int lora_gpu_box_3d1r(const double *in, double *out, const double *params, int times, int input_h,
+                      int input_m, int input_n);                                                     /* gpu_box_3d1r  3d_utils.h:44, 3d/gpu_box.cu:143 */
+int lora_gpu_star_3d1r(const double *in, double *out, const double *params, int times, int input_h,
+                       int input_m, int input_n);                                                    /* gpu_star_3d1r 3d_utils.h:47, 3d/gpu_star.cu:136 */
+
+/* Timing of the last host-buffer run, as the reference measures it (steady_clock around the
+ * launch loop + one device sync, transfers excluded: 2d/gpu.cu:542-552), plus the transfer
+ * inclusive time. */
+typedef struct lora_run_info {
+    double sweep_seconds;    /* launch loop + sync                      */
+    double total_seconds;    /* H2D + sweep + D2H                       */
+    double gstencils;        /* points*times/sweep_seconds/1e9 (F = 1)  */
+    double gstencils_refconv; /* the same times the reference's factor F */
+    double hbm_gbs;          /* algorithmic 2*sizeof(T) bytes per point */
+    int variant;             /* lora_variant actually used              */
+    int steps_per_launch;    /* 1 unless temporal fusion is active      */
+} lora_run_info;
+
+/* Generic form of group A (shape chosen at run time).  `quiet` != 0 suppresses the stdout
+ * lines; `info` may be NULL. */
+int lora_run_host(int shape, const double *in, double *out, const double *params, int times, const int *dims,
+                  int quiet, lora_run_info *info);
+/* lora_run_info of the last group-A call on this thread (what the CLIs print after the reference's lines). */
+int lora_last_run_info(lora_run_info *info);
+
+/* ========================================================================================
+ * B. Device-resident plans.
+ *    A plan fixes shape, interior dims, weights and kernel variant; it owns no grid memory.
+ *    Buffers are PADDED device arrays laid out like the host arrays of group A; `stream` is a
+ *    hipStream_t passed as void* (NULL = the null stream).  Calls are asynchronous.
+ * ====================================================================================== */
+typedef struct lora_plan lora_plan;
+
+/* params -> effective weights exactly like the reference operator (incl. the low-rank factor
+ * precompute for box2d).  params == NULL uses the reference harness's table for the shape. */
+int lora_plan_create(lora_plan **plan, int shape, int dtype, const int *dims, const double *params);
+/* Replace the taps (9/49/27 doubles) applied per sweep, bypassing the params mapping
+ * (normalised-weights mode). */
+int lora_plan_set_weights(lora_plan *plan, const double *weights, int count);
+int lora_plan_get_weights(const lora_plan *plan, double *weights, int count);
+int lora_plan_set_variant(lora_plan *plan, int variant);
+/* Integer tuning knob for benchmarking ("rows_per_thread", "panel_width", "steps_per_launch"). */
+int lora_plan_set_option(lora_plan *plan, const char *key, int value);
+int lora_plan_get_option(const lora_plan *plan, const char *key, int *value);
+size_t lora_plan_padded_bytes(const lora_plan *plan);
+/* Name of the kernel a sweep of this plan launches (for matching rocprof rows). */
+const char *lora_plan_kernel_name(const lora_plan *plan);
+
+/* One kernel application: interior of d_out <- stencil(d_in).  Halo cells of d_out are not
+ * touched (2d/gpu.cu:266-271). */
+int lora_plan_step(lora_plan *plan, const void *d_in, void *d_out, void *stream);
+/* The same restricted to outermost-dimension interior indices [begin, end) (rows in 2D, planes
+ * in 3D, points in 1D) -- used to compute slab boundaries first and overlap the halo exchange
+ * with the rest.  begin must be a multiple of lora_plan_region_granularity() (2 in 1D, 1 otherwise). */
+int lora_plan_step_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream);
+int lora_plan_region_granularity(const lora_plan *plan);
+/* The time-step driver (2d/gpu.cu:544-546): `times` applications ping-ponging between the two
+ * buffers starting from d_buf0; the result is in buffer [times % 2].  The caller must have put
+ * the padded input in d_buf0 and zeros in d_buf1 to get the reference semantics. */
+int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream);
+void lora_plan_destroy(lora_plan *plan);
+
+/* ========================================================================================
+ * C. Host helpers on the path.
+ * ====================================================================================== */
+/* The params tables the reference harness builds (1d/main.cu:77-78, 2d/main.cu:139-195,
+ * 3d/main.cu:112-125).  Returns the tap count. */
+int lora_default_params(int shape, double *params);
+/* The taps the reference operator applies for `params` (see group A).  Returns the count. */
+int lora_effective_weights(int shape, const double *params, double *weights);
+/* Low-rank factor precompute of the box2d operator (2d/gpu.cu:280-350): pyramid peeling of a
+ * symmetric 7x7 matrix into rank-1 terms u[t] (x) v[t], t = 0..3 (4x7 doubles each, row-major).
+ * `residual_max` (nullable) receives max |params - sum_{t<3} u_t v_t^T|: the part the
+ * reference silently drops. */
+int lora_factorize_7x7(const double *params, double *u, double *v, double *residual_max);
+
+/* glibc rand() stream (TYPE_3, seed 1 = the reference's un-seeded rand()) so that inputs are
+ * identical on any libc.  Fill = (double)(rand() % mod): 1d/main.cu:105-109 (mod 10000),
+ * 2d/main.cu:232-236 and 3d/main.cu:164-168 (mod 100). */
+typedef struct lora_rng {
+    int32_t r[34];
+    int32_t pos;
+} lora_rng;
+void lora_rng_seed(lora_rng *g, unsigned seed);
+int lora_rng_next(lora_rng *g);
+void lora_fill_rand(double *dst, size_t count, int mod, lora_rng *g);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LORASTENCIL_H */

@@ -1,0 +1,421 @@
+// capi.cpp -- implementation of the C ABI in include/lorastencil.h: plans, the time-step driver and the
+// host-buffer operators that stand in for the reference's gpu_*() functions.
+//
+// Reference behaviour followed (file:line under /root/reference/src/):
+//   driver: buf0 <- padded input, buf1 <- 0, `times` launches ping-ponging, result = buf[times % 2],
+//           timing = steady_clock around the launch loop + one device sync
+//           (1d/gpu_1r.cu:103-134, 2d/gpu.cu:392-421, :450-479, :525-554, 3d/gpu_star.cu:158-192,
+//            3d/gpu_box.cu:190-223)
+//   stdout: label / "Time = <ms>[ms]" / "GStencil/s = %f" (e.g. 2d/gpu.cu:549-553)
+// There is deliberately no CPU fallback: without a HIP device every compute entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+
+#include "engine.h"
+
+namespace lora {
+
+static thread_local std::string g_last_error;
+static thread_local lora_run_info g_last_info = {};
+
+void set_last_error(const char *what, hipError_t e) {
+    g_last_error = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
+}
+
+#define LORA_HIP_TRY(expr)                      \
+    do {                                        \
+        hipError_t e__ = (expr);                \
+        if (e__ != hipSuccess) {                \
+            lora::set_last_error(#expr, e__);   \
+            return LORA_EHIP;                   \
+        }                                       \
+    } while (0)
+
+static int outer_extent(const Plan &p) { return p.dims[0]; }
+
+int region_granularity(const Plan &p) {
+    switch (p.ndim) {
+        case 1:
+            return 2;
+        default:
+            return 1;  // 2D tiles and 3D chunks may start on any row / plane
+    }
+}
+
+void plan_refresh(Plan &p) {
+    if (p.ndim == 2) {
+        // smallest tap set that covers the non-zero pattern of the applied taps
+        bool diamond = true, star = true;
+        for (int r = 0; r < 7; ++r)
+            for (int c = 0; c < 7; ++c) {
+                if (p.w[r * 7 + c] == 0.0) continue;
+                const int ar = r < 3 ? 3 - r : r - 3, ac = c < 3 ? 3 - c : c - 3;
+                if (ar != 0 && ac != 0) star = false;
+                if (ar + ac > 3) diamond = false;
+            }
+        p.tapset = star ? TAPS2D_STAR : (diamond ? TAPS2D_DIAMOND : TAPS2D_BOX);
+        p.kernel_name = (p.variant == LORA_VARIANT_MFMA) ? kernel_name_2d_mfma(p) : kernel_name_2d_direct(p);
+    } else if (p.ndim == 3) {
+        bool star = true;
+        for (int k = 0; k < 27; ++k) {
+            if (p.w[k] == 0.0) continue;
+            const int dz = k / 9, dy = (k / 3) % 3, dx = k % 3;
+            if ((dz != 1) + (dy != 1) + (dx != 1) > 1) star = false;
+        }
+        p.tapset = star ? TAPS3D_STAR : TAPS3D_BOX;
+        p.kernel_name = kernel_name_3d(p);
+    } else {
+        p.tapset = 0;
+        p.kernel_name = kernel_name_1d(p);
+    }
+}
+
+static int check_buffers(const void *a, const void *b) {
+    if (!a || !b) return LORA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(b) & 15)) {
+        g_last_error = "device buffers must be 16-byte aligned";
+        return LORA_EUNSUPPORTED;
+    }
+    return LORA_OK;
+}
+
+static int step_region(Plan &p, const void *d_in, void *d_out, int begin, int end, hipStream_t s) {
+    if (int rc = check_buffers(d_in, d_out)) return rc;
+    if (d_in == d_out) return LORA_EINVAL;
+    const int ext = outer_extent(p);
+    if (begin < 0 || end > ext || begin > end) return LORA_EINVAL;
+    const int g = region_granularity(p);
+    if (begin % g != 0) return LORA_EINVAL;
+    const double *in = static_cast<const double *>(d_in);
+    double *out = static_cast<double *>(d_out);
+    hipError_t e;
+    if (p.ndim == 1)
+        e = launch_1d(p, in, out, begin, end, s);
+    else if (p.ndim == 2)
+        e = (p.variant == LORA_VARIANT_MFMA) ? launch_2d_mfma(p, in, out, begin, end, s)
+                                             : launch_2d_direct(p, in, out, begin, end, s);
+    else
+        e = launch_3d(p, in, out, begin, end, s);
+    if (e != hipSuccess) {
+        set_last_error("kernel launch", e);
+        return LORA_EHIP;
+    }
+    return LORA_OK;
+}
+
+}  // namespace lora
+
+using lora::g_last_error;
+using lora::Plan;
+
+extern "C" {
+
+const char *lora_strerror(int status) {
+    switch (status) {
+        case LORA_OK:
+            return "ok";
+        case LORA_EINVAL:
+            return "invalid argument";
+        case LORA_EUNSUPPORTED:
+            return "unsupported size or alignment";
+        case LORA_EHIP:
+            return "HIP runtime error";
+        case LORA_ENOMEM:
+            return "out of memory";
+        case LORA_ENODEVICE:
+            return "no HIP device (this engine has no CPU fallback)";
+        default:
+            return "unknown status";
+    }
+}
+
+const char *lora_last_error(void) { return g_last_error.c_str(); }
+
+int lora_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void) hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, const double *params) {
+    if (!out || !dims) return LORA_EINVAL;
+    *out = nullptr;
+    const int nd = lora::shape_ndim(shape);
+    if (nd == 0 || dtype != LORA_F64) return LORA_EINVAL;
+    for (int d = 0; d < nd; ++d)
+        if (dims[d] <= 0) return LORA_EINVAL;
+    // 2D/3D rows are read and written in 16-byte pieces: the innermost extent must be even
+    if (nd >= 2 && (dims[nd - 1] & 1)) {
+        g_last_error = "innermost extent must be even";
+        return LORA_EUNSUPPORTED;
+    }
+    if ((double) lora_padded_count(shape, dims) >= 2147483647.0 * 64) return LORA_EUNSUPPORTED;
+    lora_plan *pl = new (std::nothrow) lora_plan();
+    if (!pl) return LORA_ENOMEM;
+    Plan &p = pl->p;
+    p.shape = shape;
+    p.ndim = nd;
+    p.dtype = dtype;
+    for (int d = 0; d < nd; ++d) p.dims[d] = dims[d];
+    p.ntaps = lora::shape_ntaps(shape);
+    double tmp[49];
+    if (!params) {
+        lora::default_params(shape, tmp);
+        params = tmp;
+    }
+    lora::effective_weights(shape, params, p.w);
+    p.variant = LORA_VARIANT_DIRECT;
+    if (nd == 3) {
+        // enough workgroups to fill 256 CUs a few times over, chunks as long as that allows
+        const long tiles = (long) ((dims[2] + 127) / 128) * ((dims[1] + 15) / 16);
+        int zc = 16;
+        while (zc > 4 && tiles * ((dims[0] + zc - 1) / zc) < 2048) zc = (zc == 16) ? 7 : 4;
+        p.z_chunk = zc;
+    }
+    lora::plan_refresh(p);
+    *out = pl;
+    return LORA_OK;
+}
+
+void lora_plan_destroy(lora_plan *plan) { delete plan; }
+
+int lora_plan_set_weights(lora_plan *plan, const double *weights, int count) {
+    if (!plan || !weights || count != plan->p.ntaps) return LORA_EINVAL;
+    std::memcpy(plan->p.w, weights, sizeof(double) * count);
+    lora::plan_refresh(plan->p);
+    return LORA_OK;
+}
+
+int lora_plan_get_weights(const lora_plan *plan, double *weights, int count) {
+    if (!plan || !weights || count != plan->p.ntaps) return LORA_EINVAL;
+    std::memcpy(weights, plan->p.w, sizeof(double) * count);
+    return LORA_OK;
+}
+
+int lora_plan_set_variant(lora_plan *plan, int variant) {
+    if (!plan) return LORA_EINVAL;
+    if (variant == LORA_VARIANT_AUTO) variant = LORA_VARIANT_DIRECT;
+    if (variant == LORA_VARIANT_MFMA && plan->p.ndim != 2) return LORA_EUNSUPPORTED;
+    if (variant != LORA_VARIANT_DIRECT && variant != LORA_VARIANT_MFMA) return LORA_EINVAL;
+    plan->p.variant = variant;
+    lora::plan_refresh(plan->p);
+    return LORA_OK;
+}
+
+int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
+    if (!plan || !key) return LORA_EINVAL;
+    Plan &p = plan->p;
+    if (!std::strcmp(key, "rows_per_thread")) {
+        if (value != 4 && value != 8 && value != 16) return LORA_EINVAL;
+        p.rows_per_thread = value;
+    } else if (!std::strcmp(key, "panel_width")) {
+        if (value < 1) return LORA_EINVAL;
+        p.panel_width = value;
+    } else if (!std::strcmp(key, "z_chunk")) {
+        if (value < 1) return LORA_EINVAL;
+        p.z_chunk = value;
+    } else if (!std::strcmp(key, "steps_per_launch")) {
+        if (value != 1) return LORA_EUNSUPPORTED;
+        p.steps_per_launch = value;
+    } else {
+        return LORA_EINVAL;
+    }
+    lora::plan_refresh(p);
+    return LORA_OK;
+}
+
+int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
+    if (!plan || !key || !value) return LORA_EINVAL;
+    const Plan &p = plan->p;
+    if (!std::strcmp(key, "rows_per_thread"))
+        *value = p.rows_per_thread;
+    else if (!std::strcmp(key, "panel_width"))
+        *value = p.panel_width;
+    else if (!std::strcmp(key, "z_chunk"))
+        *value = p.z_chunk;
+    else if (!std::strcmp(key, "steps_per_launch"))
+        *value = p.steps_per_launch;
+    else if (!std::strcmp(key, "tapset"))
+        *value = p.tapset;
+    else if (!std::strcmp(key, "variant"))
+        *value = p.variant;
+    else
+        return LORA_EINVAL;
+    return LORA_OK;
+}
+
+size_t lora_plan_padded_bytes(const lora_plan *plan) {
+    if (!plan) return 0;
+    return lora_padded_count(plan->p.shape, plan->p.dims) * sizeof(double);
+}
+
+const char *lora_plan_kernel_name(const lora_plan *plan) { return plan ? plan->p.kernel_name.c_str() : ""; }
+
+int lora_plan_region_granularity(const lora_plan *plan) { return plan ? lora::region_granularity(plan->p) : 0; }
+
+int lora_plan_step_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream) {
+    if (!plan) return LORA_EINVAL;
+    return lora::step_region(plan->p, d_in, d_out, begin, end, static_cast<hipStream_t>(stream));
+}
+
+int lora_plan_step(lora_plan *plan, const void *d_in, void *d_out, void *stream) {
+    if (!plan) return LORA_EINVAL;
+    return lora::step_region(plan->p, d_in, d_out, 0, plan->p.dims[0], static_cast<hipStream_t>(stream));
+}
+
+int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream) {
+    if (!plan || times < 0) return LORA_EINVAL;
+    void *buf[2] = {d_buf0, d_buf1};
+    for (int i = 0; i < times; ++i) {  // 2d/gpu.cu:544-546
+        const int rc = lora_plan_step(plan, buf[i % 2], buf[(i + 1) % 2], stream);
+        if (rc != LORA_OK) return rc;
+    }
+    return LORA_OK;
+}
+
+// ---- group A: host-buffer operators ------------------------------------------------------------------
+
+static const char *run_label(int shape) {
+    switch (shape) {
+        case LORA_1D1R:
+            return "LoRAStencil(1D 1d1r): ";  // 1d/gpu_1r.cu:127
+        case LORA_1D2R:
+            return "LoRAStencil(1D 1d2r): ";  // 1d/gpu_2r.cu:129
+        case LORA_STAR2D1R:
+            return "LoRAStencil(2D star_2d1r): ";  // 2d/gpu.cu:549
+        case LORA_STAR2D3R:
+            return "LoRAStencil(2D star_2d3r): ";  // 2d/gpu.cu:474
+        case LORA_BOX2D1R:
+        case LORA_BOX2D3R:
+            return "LoRAStencil(2D box_2d3r): ";  // 2d/gpu.cu:415 (one operator serves both box shapes)
+        case LORA_STAR3D1R:
+            return "LoRAStencil(3D star_3d1r): ";  // 3d/gpu_star.cu:185
+        case LORA_BOX3D1R:
+            return "LoRAStencil(3D box_3d1r): ";  // 3d/gpu_box.cu:216
+        default:
+            return "LoRAStencil(?): ";
+    }
+}
+
+namespace {
+struct DeviceBuffers {
+    void *b[2] = {nullptr, nullptr};
+    ~DeviceBuffers() {
+        for (void *p : b)
+            if (p) (void) hipFree(p);
+    }
+};
+}  // namespace
+
+int lora_run_host(int shape, const double *in, double *out, const double *params, int times, const int *dims,
+                  int quiet, lora_run_info *info) {
+    if (!in || !out || !dims || times < 0) return LORA_EINVAL;
+    if (lora_device_count() <= 0) {
+        g_last_error = "no HIP device visible";
+        return LORA_ENODEVICE;
+    }
+    lora_plan *plan = nullptr;
+    int rc = lora_plan_create(&plan, shape, LORA_F64, dims, params);
+    if (rc != LORA_OK) return rc;
+    struct PlanGuard {
+        lora_plan *p;
+        ~PlanGuard() { lora_plan_destroy(p); }
+    } guard{plan};
+
+    using clock = std::chrono::steady_clock;
+    const size_t count = lora_padded_count(shape, dims);
+    const size_t bytes = count * sizeof(double);
+    DeviceBuffers dev;
+    const auto t_total0 = clock::now();
+    LORA_HIP_TRY(hipMalloc(&dev.b[0], bytes));
+    LORA_HIP_TRY(hipMalloc(&dev.b[1], bytes));
+    LORA_HIP_TRY(hipMemcpy(dev.b[0], in, bytes, hipMemcpyHostToDevice));  // whole padded input, halo included
+    // warm-up (the reference has none): one sweep into buf1, which is then cleared again
+    if (times > 0) {
+        rc = lora_plan_step(plan, dev.b[0], dev.b[1], nullptr);
+        if (rc != LORA_OK) return rc;
+    }
+    LORA_HIP_TRY(hipMemset(dev.b[1], 0, bytes));
+    LORA_HIP_TRY(hipDeviceSynchronize());
+
+    const auto t0 = clock::now();
+    rc = lora_plan_run(plan, dev.b[0], dev.b[1], times, nullptr);
+    if (rc != LORA_OK) return rc;
+    LORA_HIP_TRY(hipDeviceSynchronize());
+    const auto t1 = clock::now();
+
+    // 1D copies all but the last element (1d/gpu_1r.cu:134)
+    const size_t copy_bytes = (plan->p.ndim == 1) ? bytes - sizeof(double) : bytes;
+    LORA_HIP_TRY(hipMemcpy(out, dev.b[times % 2], copy_bytes, hipMemcpyDeviceToHost));
+    const auto t_total1 = clock::now();
+
+    double points = 1.0;
+    for (int d = 0; d < plan->p.ndim; ++d) points *= dims[d];
+    const long long us = std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+    const double secs = us / 1e6;
+    const int F = lora_shape_gstencil_factor(shape);
+    lora_run_info ri;
+    ri.sweep_seconds = std::chrono::duration<double>(t1 - t0).count();
+    ri.total_seconds = std::chrono::duration<double>(t_total1 - t_total0).count();
+    ri.gstencils = points * times / ri.sweep_seconds / 1e9;
+    ri.gstencils_refconv = ri.gstencils * F;
+    ri.hbm_gbs = points * times * 2.0 * sizeof(double) / ri.sweep_seconds / 1e9;
+    ri.variant = plan->p.variant;
+    ri.steps_per_launch = plan->p.steps_per_launch;
+    lora::g_last_info = ri;
+    if (info) *info = ri;
+    if (!quiet) {
+        // byte-compatible with the reference's three lines (2d/gpu.cu:549-553)
+        std::printf("%s\n", run_label(shape));
+        std::printf("Time = %lld[ms]\n",
+                    (long long) std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count());
+        std::printf("GStencil/s = %f\n", points * times * F / secs / 1e9);
+        std::fflush(stdout);
+    }
+    return LORA_OK;
+}
+
+int lora_last_run_info(lora_run_info *info) {
+    if (!info) return LORA_EINVAL;
+    *info = lora::g_last_info;
+    return LORA_OK;
+}
+
+int lora_gpu_1d1r(const double *in, double *out, const double *params, int times, int n) {
+    const int dims[1] = {n};
+    return lora_run_host(LORA_1D1R, in, out, params, times, dims, 0, nullptr);
+}
+int lora_gpu_1d2r(const double *in, double *out, const double *params, int times, int n) {
+    const int dims[1] = {n};
+    return lora_run_host(LORA_1D2R, in, out, params, times, dims, 0, nullptr);
+}
+int lora_gpu_star_2d1r(const double *in, double *out, const double *params, int times, int m, int n) {
+    const int dims[2] = {m, n};
+    return lora_run_host(LORA_STAR2D1R, in, out, params, times, dims, 0, nullptr);
+}
+int lora_gpu_star_2d3r(const double *in, double *out, const double *params, int times, int m, int n) {
+    const int dims[2] = {m, n};
+    return lora_run_host(LORA_STAR2D3R, in, out, params, times, dims, 0, nullptr);
+}
+int lora_gpu_box_2d3r(const double *in, double *out, const double *params, int times, int m, int n) {
+    const int dims[2] = {m, n};
+    return lora_run_host(LORA_BOX2D3R, in, out, params, times, dims, 0, nullptr);
+}
+int lora_gpu_box_3d1r(const double *in, double *out, const double *params, int times, int h, int m, int n) {
+    const int dims[3] = {h, m, n};
+    return lora_run_host(LORA_BOX3D1R, in, out, params, times, dims, 0, nullptr);
+}
+int lora_gpu_star_3d1r(const double *in, double *out, const double *params, int times, int h, int m, int n) {
+    const int dims[3] = {h, m, n};
+    return lora_run_host(LORA_STAR3D1R, in, out, params, times, dims, 0, nullptr);
+}
+
+}  // extern "C"

@@ -1,0 +1,217 @@
+// cli_main.cpp -- the three command-line harnesses lorastencil_1d / lorastencil_2d / lorastencil_3d
+// (built three times with -DLORA_CLI_DIM=1|2|3).
+//
+// Keeps the reference's positional surface and stdout (1d/main.cu:43-181, 2d/main.cu:97-337,
+// 3d/main.cu:71-253): `shape sizes... time_size`, the help text and exit code 1 on a bad shape or too few
+// arguments, std::stoi semantics and messages for the integers, the INFO line, then the operator's three lines.
+// Additions are optional trailing flags, so every reference invocation still works:
+//   --check            run the reference's CHECK_ERROR self-check (one sweep against a naive CPU loop, 1e-7 abs)
+//   --fill=random|index|ones   the reference's FILL_RANDOM / FILL_INDEX / default fills (compile-time macros there)
+//   --no-extra         print nothing beyond the reference's own lines
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "lorastencil.h"
+#include "lorastencil_ref_shims.h"
+
+#ifndef LORA_CLI_DIM
+#error "build with -DLORA_CLI_DIM=1, 2 or 3"
+#endif
+
+// naive one-sweep CPU loops used ONLY by --check (cli_selfcheck.cpp); never a fallback for the GPU path
+long selfcheck_compare(int shape, const std::vector<double> &input, const double *params, const int *dims);
+
+namespace {
+
+constexpr int kDim = LORA_CLI_DIM;
+
+void print_help() {
+#if LORA_CLI_DIM == 1
+    const char *msg =
+        "Program name: lorastencil_1d\n"
+        "Usage: lorastencil_1d shape input_size time_size\n"
+        "Shape: 1d1r or 1d2r\n";
+#elif LORA_CLI_DIM == 2
+    const char *msg =
+        "Program name: lorastencil_2d\n"
+        "Usage: lorastencil_2d shape input_size_of_first_dimension input_size_of_second_dimension time_size\n"
+        "Shape: box2d1r or star2d1r or box2d3r or star2d3r\n";
+#else
+    const char *msg =
+        "Program name: lorastencil_3d\n"
+        "Usage: lorastencil_3d shape input_size_of_first_dimension input_size_of_second_dimension "
+        "input_size_of_third_dimension time_size\n"
+        "Shape: box3d1r or star3d1r\n";
+#endif
+    std::printf("%s\n", msg);
+}
+
+enum class Fill { Random, Index, Ones };
+
+void fill_input(std::vector<double> &a, int shape, const int *dims, Fill fill) {
+    const size_t count = a.size();
+    if (fill == Fill::Random) {
+        lora_rng g;
+        lora_rng_seed(&g, 1);  // the reference never calls srand()
+        if (kDim == 1) {
+            // 1d/main.cu:107 draws cols + 1 values (the last one lands past its allocation)
+            lora_fill_rand(a.data(), count, 10000, &g);
+            (void) lora_rng_next(&g);
+        } else {
+            lora_fill_rand(a.data(), count, 100, &g);
+        }
+        return;
+    }
+    if (fill == Fill::Index) {  // FILL_INDEX: interior = linear interior index, halo 0
+        std::fill(a.begin(), a.end(), 0.0);
+        if (kDim == 1) {
+            for (int i = 0; i < dims[0]; ++i) a[i + 4] = i;
+        } else if (kDim == 2) {
+            const size_t ld = dims[1] + 8;
+            for (int i = 0; i < dims[0]; ++i)
+                for (int j = 0; j < dims[1]; ++j) a[(i + 4) * ld + j + 4] = (double) ((size_t) i * dims[1] + j);
+        } else {
+            const size_t ld = dims[2] + 8, plane = (size_t) (dims[1] + 4) * ld;
+            for (int k = 0; k < dims[0]; ++k)
+                for (int i = 0; i < dims[1]; ++i)
+                    for (int j = 0; j < dims[2]; ++j)
+                        a[(k + 1) * plane + (i + 2) * ld + j + 4] =
+                            (double) (((size_t) k * dims[1] + i) * dims[2] + j);
+        }
+        return;
+    }
+    // the reference's default branch: ones (2D leaves the last column of every row at 0, 2d/main.cu:246-253)
+    std::fill(a.begin(), a.end(), 1.0);
+    if (kDim == 2) {
+        const size_t ld = dims[1] + 8;
+        for (int i = 0; i < dims[0] + 8; ++i) a[i * ld + ld - 1] = 0.0;
+    }
+    (void) shape;
+}
+
+}  // namespace
+
+int main(int argc, char *argv[]) {
+    if (argc < kDim + 3) {  // 1d/main.cu:44, 2d/main.cu:98, 3d/main.cu:72
+        print_help();
+        return 1;
+    }
+    const int shape = lora_shape_from_name(argv[1]);
+    if (shape < 0 || lora_shape_ndim(shape) != kDim) {
+        print_help();
+        return 1;
+    }
+
+    int dims[3] = {0, 0, 0};
+    int times = 0;
+    try {
+        for (int d = 0; d < kDim; ++d) dims[d] = std::stoi(argv[2 + d]);
+        times = std::stoi(argv[2 + kDim]);
+    } catch (const std::invalid_argument &) {
+        std::cerr << "Invalid argument: cannot convert the parameter(s) to integer.\n";
+        return 1;
+    } catch (const std::out_of_range &) {
+        std::cerr << "Argument out of range: the parameter(s) is(are) too large.\n";
+        return 1;
+    }
+
+    bool check = false, extra = true;
+    Fill fill = Fill::Random;
+    for (int i = kDim + 3; i < argc; ++i) {
+        const std::string a = argv[i];
+        if (a == "--check")
+            check = true;
+        else if (a == "--no-extra")
+            extra = false;
+        else if (a == "--fill=random")
+            fill = Fill::Random;
+        else if (a == "--fill=index")
+            fill = Fill::Index;
+        else if (a == "--fill=ones")
+            fill = Fill::Ones;
+        else {
+            std::cerr << "Unknown option: " << a << "\n";
+            return 1;
+        }
+    }
+
+    double params[49];
+    lora_default_params(shape, params);
+
+    const char *name = lora_shape_info_name(shape);
+    if (kDim == 1)
+        std::printf("INFO: shape = %s, n = %d, times = %d\n", name, dims[0], times);
+    else if (kDim == 2)
+        std::printf("INFO: shape = %s, m = %d, n = %d, times = %d\n", name, dims[0], dims[1], times);
+    else
+        std::printf("INFO: shape = %s, h = %d, m = %d, n = %d, times = %d\n", name, dims[0], dims[1], dims[2], times);
+
+    for (int d = 0; d < kDim; ++d) {
+        if (dims[d] <= 0) {
+            std::cerr << "Invalid argument: sizes must be positive.\n";
+            return 1;
+        }
+    }
+    if (times < 0) {
+        std::cerr << "Invalid argument: time_size must not be negative.\n";
+        return 1;
+    }
+
+    const size_t count = lora_padded_count(shape, dims);
+    std::vector<double> matrix(count, 0.0), output(count, 0.0);
+    fill_input(matrix, shape, dims, fill);
+
+    if (check) {  // CHECK_ERROR prints the shape and the params first (2d/main.cu:257-265)
+        std::cout << argv[1] << std::endl;
+    }
+
+    switch (shape) {
+        case LORA_1D1R:
+            gpu_1d1r(matrix.data(), output.data(), params, times, dims[0]);
+            break;
+        case LORA_1D2R:
+            gpu_1d2r(matrix.data(), output.data(), params, times, dims[0]);
+            break;
+        case LORA_STAR2D1R:
+            gpu_star_2d1r(matrix.data(), output.data(), params, times, dims[0], dims[1]);
+            break;
+        case LORA_STAR2D3R:
+            gpu_star_2d3r(matrix.data(), output.data(), params, times, dims[0], dims[1]);
+            break;
+        case LORA_BOX2D1R:
+        case LORA_BOX2D3R:
+            gpu_box_2d3r(matrix.data(), output.data(), params, times, dims[0], dims[1]);
+            break;
+        case LORA_BOX3D1R:
+            gpu_box_3d1r(matrix.data(), output.data(), params, times, dims[0], dims[1], dims[2]);
+            break;
+        case LORA_STAR3D1R:
+            gpu_star_3d1r(matrix.data(), output.data(), params, times, dims[0], dims[1], dims[2]);
+            break;
+    }
+
+    if (extra) {
+        lora_run_info ri;
+        if (lora_last_run_info(&ri) == LORA_OK && ri.sweep_seconds > 0) {
+            std::printf("GStencils/s (per kernel application, F=1) = %f\n", ri.gstencils);
+            std::printf("Algorithmic HBM traffic = %f GB/s (%.1f%% of 8000 GB/s)\n", ri.hbm_gbs, ri.hbm_gbs / 80.0);
+            std::printf("Total incl. transfers = %f s\n", ri.total_seconds);
+        }
+    }
+
+    if (check) {
+        std::printf("\nChecking Correctness... \n");
+        const long bad = selfcheck_compare(shape, matrix, params, dims);
+        std::printf("Correct!\n");  // unconditional in the reference (2d/main.cu:326)
+        if (bad != 0) {
+            std::fprintf(stderr, "%ld point(s) differ by more than 1e-7\n", bad);
+            return 2;  // the reference always exits 0; a failing check is worth an exit code here
+        }
+    }
+    return 0;
+}

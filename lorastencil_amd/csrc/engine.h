@@ -1,0 +1,83 @@
+// engine.h -- internal interfaces of liblorastencil_hip (not installed; the public surface is
+// include/lorastencil.h).
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include <string>
+
+#include "lorastencil.h"
+
+namespace lora {
+
+// ---- host helpers (weights.cpp) ------------------------------------------------------------
+int shape_ndim(int shape);
+int shape_ntaps(int shape);
+int default_params(int shape, double *params);
+int effective_weights(int shape, const double *params, double *weights);
+int factorize_7x7(const double *params, double u[4][7], double v[4][7], double *residual_max);
+
+// ---- tap sets: which of the 49 / 27 taps a kernel instantiation evaluates --------------------
+enum TapSet2D { TAPS2D_DIAMOND = 0, TAPS2D_STAR = 1, TAPS2D_BOX = 2 };
+enum TapSet3D { TAPS3D_STAR = 0, TAPS3D_BOX = 1 };
+
+struct Taps9 {
+    double w[9];
+};
+struct Taps49 {
+    double w[49];
+};
+struct Taps27 {
+    double w[27];
+};
+
+// Band factors of the low-rank MFMA formulation: out = sum_t (U_t X) V_t + sparse residual.
+struct LowRank2D {
+    int rank;         // 1..3 terms
+    double u[3][7];   // vertical profile of term t
+    double v[3][7];   // horizontal profile of term t
+    int nresid;       // residual taps applied on the vector pipe
+    int rdy[16], rdx[16];
+    double rw[16];
+};
+
+// ---- plan -------------------------------------------------------------------------------------
+struct Plan {
+    int shape = 0, ndim = 0, dtype = LORA_F64;
+    int dims[3] = {0, 0, 0};  // interior extents, outermost first
+    int ntaps = 0;
+    double w[49] = {0};  // taps applied per sweep
+    int variant = LORA_VARIANT_DIRECT;
+    int tapset = 0;
+    // tuning knobs (lora_plan_set_option)
+    int rows_per_thread = 8;  // 2D direct: output rows per lane (tile height = 4x this)
+    int panel_width = 8;      // 2D: tile columns per L2 panel of the block->tile map
+    int z_chunk = 16;         // 3D: output planes streamed per workgroup
+    int steps_per_launch = 1;
+    bool lowrank_valid = false;
+    LowRank2D lowrank{};
+    std::string kernel_name;
+};
+
+void plan_refresh(Plan &p);  // re-derive tapset / low-rank factors / kernel name from w + options
+
+// ---- kernel launchers (kernels_*.hip).  Interior index range [begin, end) of the outermost
+// dimension; all return the launch status. ----------------------------------------------------
+hipError_t launch_1d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+hipError_t launch_2d_direct(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+hipError_t launch_2d_mfma(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+hipError_t launch_3d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+
+const char *kernel_name_1d(const Plan &p);
+const char *kernel_name_2d_direct(const Plan &p);
+const char *kernel_name_2d_mfma(const Plan &p);
+const char *kernel_name_3d(const Plan &p);
+int region_granularity(const Plan &p);
+
+void set_last_error(const char *what, hipError_t e);
+
+}  // namespace lora
+
+struct lora_plan {
+    lora::Plan p;
+};

@@ -1,0 +1,205 @@
+"""ctypes front-end of the CPU oracle (liblorastencil_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py``.  Nothing under ``lorastencil_amd/`` imports it.
+See ``lorastencil_oracle.h`` for the reference file:line each function follows.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liblorastencil_oracle.so")
+
+SHAPES = {
+    "1d1r": 0,
+    "1d2r": 1,
+    "star2d1r": 2,
+    "box2d1r": 3,
+    "star2d3r": 4,
+    "box2d3r": 5,
+    "star3d1r": 6,
+    "box3d1r": 7,
+}
+NDIM = {0: 1, 1: 1, 2: 2, 3: 2, 4: 2, 5: 2, 6: 3, 7: 3}
+NTAPS = {1: 9, 2: 49, 3: 27}
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc if the .so is missing or stale."""
+    src = os.path.join(_HERE, "lorastencil_oracle.c")
+    hdr = os.path.join(_HERE, "lorastencil_oracle.h")
+    stale = (not os.path.exists(_LIB_PATH)) or any(
+        os.path.getmtime(p) > os.path.getmtime(_LIB_PATH) for p in (src, hdr)
+    )
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liblorastencil_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.oracle_rng_seed.argtypes = [ctypes.c_void_p, ctypes.c_uint]
+        L.oracle_rng_next.argtypes = [ctypes.c_void_p]
+        L.oracle_rng_next.restype = ctypes.c_int
+        L.oracle_fill_rand.argtypes = [_dp, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+        L.oracle_default_params.argtypes = [ctypes.c_int, _dp]
+        L.oracle_default_params.restype = ctypes.c_int
+        L.oracle_effective_weights.argtypes = [ctypes.c_int, _dp, _dp]
+        L.oracle_effective_weights.restype = ctypes.c_int
+        L.oracle_factorize_7x7.argtypes = [_dp, _dp, _dp]
+        L.oracle_step_1d.argtypes = [_dp, _dp, _dp, ctypes.c_int, ctypes.c_int]
+        L.oracle_step_2d.argtypes = [_dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.oracle_step_3d.argtypes = [_dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        L.oracle_run.argtypes = [ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _ip, ctypes.c_int]
+        L.oracle_run.restype = ctypes.c_int
+        L.oracle_run_weights.argtypes = [ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _ip, ctypes.c_int]
+        L.oracle_run_weights.restype = ctypes.c_int
+        L.oracle_padded_count.argtypes = [ctypes.c_int, _ip]
+        L.oracle_padded_count.restype = ctypes.c_size_t
+        L.oracle_max_threads.restype = ctypes.c_int
+        _lib = L
+    return _lib
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp)
+
+
+def shape_id(shape) -> int:
+    return SHAPES[shape] if isinstance(shape, str) else int(shape)
+
+
+def padded_shape(shape, dims):
+    nd = NDIM[shape_id(shape)]
+    dims = tuple(int(d) for d in dims)
+    assert len(dims) == nd
+    if nd == 1:
+        return (dims[0] + 8,)
+    if nd == 2:
+        return (dims[0] + 8, dims[1] + 8)
+    return (dims[0] + 2, dims[1] + 4, dims[2] + 8)
+
+
+def halo(shape):
+    nd = NDIM[shape_id(shape)]
+    return {1: (4,), 2: (4, 4), 3: (1, 2, 4)}[nd]
+
+
+def interior(shape, a: np.ndarray) -> np.ndarray:
+    """View of the interior points of a padded array."""
+    h = halo(shape)
+    return a[tuple(slice(k, a.shape[i] - k) for i, k in enumerate(h))]
+
+
+class Rng:
+    """glibc ``rand()`` stream (seed 1 unless given)."""
+
+    def __init__(self, seed: int = 1):
+        self._buf = ctypes.create_string_buffer(34 * 4 + 8)
+        lib().oracle_rng_seed(self._buf, seed)
+
+    def next(self) -> int:
+        return lib().oracle_rng_next(self._buf)
+
+    def fill(self, count: int, mod: int) -> np.ndarray:
+        out = np.empty(count, dtype=np.float64)
+        lib().oracle_fill_rand(_p(out), count, mod, self._buf)
+        return out
+
+
+def reference_input(shape, dims, rng: Rng | None = None) -> np.ndarray:
+    """Padded input exactly as the reference harness fills it (FILL_RANDOM, un-seeded rand())."""
+    sid = shape_id(shape)
+    rng = rng or Rng()
+    ps = padded_shape(sid, dims)
+    if NDIM[sid] == 1:
+        # 1d/main.cu:107 draws cols+1 values; the extra one lands past the allocation
+        vals = rng.fill(ps[0] + 1, 10000)
+        return vals[: ps[0]].copy()
+    return rng.fill(int(np.prod(ps)), 100).reshape(ps)
+
+
+def default_params(shape) -> np.ndarray:
+    sid = shape_id(shape)
+    p = np.zeros(49, dtype=np.float64)
+    n = lib().oracle_default_params(sid, _p(p))
+    return p[:n].copy()
+
+
+def effective_weights(shape, params=None) -> np.ndarray:
+    sid = shape_id(shape)
+    params = default_params(sid) if params is None else np.ascontiguousarray(params, dtype=np.float64)
+    w = np.zeros(49, dtype=np.float64)
+    n = lib().oracle_effective_weights(sid, _p(params), _p(w))
+    return w[:n].copy()
+
+
+def factorize_7x7(params):
+    params = np.ascontiguousarray(params, dtype=np.float64)
+    u = np.zeros((4, 7))
+    v = np.zeros((4, 7))
+    lib().oracle_factorize_7x7(_p(params), _p(u), _p(v))
+    return u, v
+
+
+def step(shape, a: np.ndarray, w: np.ndarray, out: np.ndarray | None = None, threads: int = 1) -> np.ndarray:
+    """One kernel application on a padded array; only the interior of ``out`` is written."""
+    sid = shape_id(shape)
+    nd = NDIM[sid]
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    w = np.ascontiguousarray(w, dtype=np.float64)
+    assert a.ndim == nd and w.size == NTAPS[nd]
+    if out is None:
+        out = np.zeros_like(a)
+    L = lib()
+    if nd == 1:
+        L.oracle_step_1d(_p(a), _p(out), _p(w), a.shape[0], threads)
+    elif nd == 2:
+        L.oracle_step_2d(_p(a), _p(out), _p(w), a.shape[0], a.shape[1], threads)
+    else:
+        L.oracle_step_3d(_p(a), _p(out), _p(w), a.shape[0], a.shape[1], a.shape[2], threads)
+    return out
+
+
+def run(shape, a: np.ndarray, times: int, params=None, weights=None, threads: int = 1,
+        out: np.ndarray | None = None) -> np.ndarray:
+    """The operator with the reference's driver semantics.  ``a`` is the padded input.
+
+    With ``weights`` the taps are applied as given; otherwise ``params`` (default: the
+    reference harness's table) go through ``effective_weights`` like the reference operator.
+    """
+    sid = shape_id(shape)
+    nd = NDIM[sid]
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    h = halo(sid)
+    dims = (ctypes.c_int * 3)(*[a.shape[i] - 2 * h[i] for i in range(nd)], *([0] * (3 - nd)))
+    if out is None:
+        out = np.zeros_like(a)
+    if weights is not None:
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        rc = lib().oracle_run_weights(sid, _p(a), _p(out), _p(w), times, dims, threads)
+    else:
+        p = default_params(sid) if params is None else np.ascontiguousarray(params, dtype=np.float64)
+        rc = lib().oracle_run(sid, _p(a), _p(out), _p(p), times, dims, threads)
+    if rc != 0:
+        raise ValueError(f"oracle_run failed (shape={shape}, times={times})")
+    return out
+
+
+def max_threads() -> int:
+    return lib().oracle_max_threads()
