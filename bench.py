@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GStencils/s of the stencil sweep, star2d1r 16384 x 16384 fp64 (BASELINE.json configs[1]),
+on N MI355X GPUs of one node.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one kernel application (one sweep of the whole grid): the reference's time-step loop body
+(2d/gpu.cu:544-546).  `value` counts interior points x applications per second with F = 1 (the reference's own
+printout multiplies by 3 for this shape, 2d/gpu.cu:553; that figure is reported as `value_reference_convention`).
+Inputs are synthetic small integers (0..99, the range of the reference's rand()%100 fill) generated on the device
+and resident in HBM before the timed region.  For N > 1 the SAME 16384^2 grid is cut into N row slabs ("strong"
+scaling, as BASELINE.json quotes the metric) with one RCCL halo exchange per step overlapped with the interior.
+
+The single JSON line also carries
+  roofline      algorithmic bytes (2 x 8 B per interior point per sweep) / average launch duration
+                measured with HIP events on the launch stream, against the 8 TB/s HBM3E peak;
+  cpu_baseline  the CPU oracle (a port of the reference's test_cpu loop) timed on this box's host cores on a
+                bounded sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec; ~6.3 TB/s achievable copy)
+OVERFLOW_STEPS = {"star2d1r": 140, "box2d3r": 120, "box2d1r": 120, "star2d3r": 200, "star3d1r": 300, "box3d1r": 180,
+                  "1d1r": 240, "1d2r": 200}
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shape", default="star2d1r")
+    ap.add_argument("--size", type=int, nargs="+", default=None, help="interior sizes (default: the BASELINE config)")
+    ap.add_argument("--option", action="append", default=[], help="plan option key=value (e.g. rows_per_thread=4)")
+    ap.add_argument("--variant", choices=["auto", "direct", "mfma"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
+    return ap.parse_args()
+
+
+DEFAULT_SIZES = {"star2d1r": (16384, 16384), "box2d3r": (8192, 8192), "box2d1r": (8192, 8192), "star2d3r": (16384, 16384),
+                 "star3d1r": (512, 512, 512), "box3d1r": (768, 768, 768), "1d1r": (1048576,), "1d2r": (1048576,)}
+
+
+def cpu_baseline(shape, dims, budget_s):
+    """Oracle (CPU restatement of the reference's naive loop) on a bounded sample: the first rows/planes of the same
+    grid, all host threads, at least one full sweep of the sample."""
+    import numpy as np
+
+    from oracle import oracle as O
+
+    threads = O.max_threads()
+    w = O.effective_weights(shape)
+    inner = 1
+    for d in dims[1:]:
+        inner *= d
+    rng = np.random.default_rng(0)
+    # calibrate on a thin slab, then size the sample so that one sweep takes about a quarter of the budget
+    n_cal = int(max(8, min(dims[0], (4 << 20) // max(inner, 1))))
+    cal = rng.integers(0, 100, O.padded_shape(shape, (n_cal,) + tuple(dims[1:]))).astype(np.float64)
+    cal_out = np.zeros_like(cal)
+    O.step(shape, cal, w, out=cal_out, threads=threads)
+    tc = time.perf_counter()
+    O.step(shape, cal, w, out=cal_out, threads=threads)
+    rate = n_cal * inner / max(time.perf_counter() - tc, 1e-6)  # points per second
+    n0 = int(max(n_cal, min(dims[0], rate * budget_s / 4.0 // max(inner, 1))))
+    sdims = (n0,) + tuple(dims[1:])
+    a = rng.integers(0, 100, O.padded_shape(shape, sdims)).astype(np.float64)
+    out = np.zeros_like(a)
+    O.step(shape, a, w, out=out, threads=threads)  # warm-up (page faults, thread pool)
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        O.step(shape, a, w, out=out, threads=threads)
+        reps += 1
+        el = time.perf_counter() - t0
+        if el > budget_s / 2 or reps >= 50:
+            break
+    pts = 1
+    for d in sdims:
+        pts *= d
+    val = pts * reps / el / 1e9
+    # single-thread figure on a smaller piece (the reference's test_cpu is single-threaded)
+    n1 = max(4, n0 // max(2 * threads, 1))
+    a1 = a[: n1 + (a.shape[0] - n0)]
+    o1 = np.zeros_like(a1)
+    t1 = time.perf_counter()
+    O.step(shape, np.ascontiguousarray(a1), w, out=o1, threads=1)
+    el1 = time.perf_counter() - t1
+    pts1 = n1 * inner
+    return {
+        "value": round(val, 4),
+        "unit": "GStencils/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{shape} sub-grid {'x'.join(str(d) for d in sdims)} of the {'x'.join(str(d) for d in dims)} "
+                  f"workload, {reps} sweeps, OpenMP over rows, same taps/order as the reference's test_cpu",
+        "value_1thread": round(pts1 / el1 / 1e9, 4),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import lorastencil_amd as L
+    from lorastencil_amd import slab
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    shape = args.shape
+    dims = tuple(args.size) if args.size else DEFAULT_SIZES[shape]
+    K, W = args.steps, args.warmup
+    opts = dict(kv.split("=") for kv in args.option)
+    variant = {"auto": L.VARIANT_AUTO, "direct": L.VARIANT_DIRECT, "mfma": L.VARIANT_MFMA}[args.variant]
+
+    # taps: the operator's own; if the run is longer than the fp64 range allows use the normalised taps
+    weights = L.effective_weights(shape)
+    normalised = (K + W) > OVERFLOW_STEPS.get(shape, 100)
+    if normalised:
+        weights = weights / weights.sum()
+
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if world == 1:
+        plan = L.Plan(shape, dims).set_weights(weights)
+        if variant != L.VARIANT_AUTO:
+            plan.set_variant(variant)
+        for k, v in opts.items():
+            plan.set_option(k, int(v))
+        ps = plan.padded_shape
+        src0 = torch.randint(0, 100, ps, generator=gen, device=dev).to(torch.float64)
+        b0, b1 = src0.clone(), torch.zeros(ps, dtype=torch.float64, device=dev)
+        run = lambda n: plan.run(b0, b1, n)  # noqa: E731
+        kernel = plan.kernel_name
+        local_points = 1
+        for d in dims:
+            local_points *= d
+
+        def reset():
+            b0.copy_(src0)
+            b1.zero_()
+    else:
+        drv = slab.SlabDriver(shape, dims, device=dev, weights=weights)
+        plan = drv.stepper.plan
+        if variant != L.VARIANT_AUTO:
+            plan.set_variant(variant)
+        for k, v in opts.items():
+            plan.set_option(k, int(v))
+        src0 = torch.randint(0, 100, drv.local_padded_shape, generator=gen, device=dev).to(torch.float64)
+        run = lambda n: drv.run(n)  # noqa: E731
+        kernel = plan.kernel_name
+        local_points = 1
+        for d in drv.layout.local_dims:
+            local_points *= d
+
+        def reset():
+            drv.buf[0].copy_(src0)
+            drv.buf[1].zero_()
+            drv.steps_done = 0
+            # neighbours' halos of time level 0
+            works = drv._post_exchange(drv.buf[0])
+            for wk in works:
+                wk.wait()
+
+    reset()
+    run(W)
+    reset()  # keep the value range of the timed steps independent of the warm-up length
+    barrier()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    run(K)
+    ev1.record()
+    barrier()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    ev_ms = ev0.elapsed_time(ev1)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    points = 1
+    for d in dims:
+        points *= d
+    value = points * K / elapsed / 1e9
+    launch_s = ev_ms / 1e3 / K  # average duration of one sweep launch on the launch stream (HIP events)
+    achieved = local_points * 16.0 / launch_s / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get(f"{shape}:{'x'.join(map(str, dims))}:{world}")
+        except Exception:
+            traffic = None
+
+    if rank == 0:
+        res = {
+            "metric": "GStencils/s",
+            "value": round(value, 3),
+            "unit": "GStencils/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": round(elapsed * 1e3 / K, 6),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{shape} {'x'.join(map(str, dims))} fp64, {K} sweeps (lorastencil_{len(dims)}d {shape} "
+                            f"{' '.join(map(str, dims))} {K})",
+                "parallelism": f"row-slabs x{world}" if world > 1 else "single GPU",
+                "kernel": kernel,
+                "variant": {1: "direct", 2: "mfma"}.get(plan.get_option("variant"), "?"),
+                "normalised_taps": bool(normalised),
+            },
+            "value_reference_convention": round(value * L.ops.gstencil_factor(shape), 3),
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "launch_us": round(launch_s * 1e6, 2),
+                "bytes_per_launch": local_points * 16,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(shape, dims, args.cpu_seconds)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

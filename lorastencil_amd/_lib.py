@@ -1,0 +1,121 @@
+"""ctypes loader for the HIP engine (lib/liblorastencil_hip.so, C ABI of include/lorastencil.h).
+
+There is no Python or CPU implementation behind this module: if the shared library has not been built
+(``python -c "import __graft_entry__ as g; g.build()"`` or ``make -C lorastencil_amd/csrc``) loading fails
+loudly, and without a HIP device every compute entry point returns ``LORA_ENODEVICE`` / a HIP error, which
+``check()`` raises as ``LoraError``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblorastencil_hip.so")
+
+LORA_OK = 0
+LORA_EINVAL = -1
+LORA_EUNSUPPORTED = -2
+LORA_EHIP = -3
+LORA_ENOMEM = -4
+LORA_ENODEVICE = -5
+
+F64 = 0
+VARIANT_AUTO, VARIANT_DIRECT, VARIANT_MFMA = 0, 1, 2
+
+_dp = ctypes.POINTER(ctypes.c_double)
+_ip = ctypes.POINTER(ctypes.c_int)
+_vp = ctypes.c_void_p
+
+
+class LoraError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        super().__init__(f"{where}: status {status} ({detail})")
+
+
+class RunInfo(ctypes.Structure):
+    _fields_ = [
+        ("sweep_seconds", ctypes.c_double),
+        ("total_seconds", ctypes.c_double),
+        ("gstencils", ctypes.c_double),
+        ("gstencils_refconv", ctypes.c_double),
+        ("hbm_gbs", ctypes.c_double),
+        ("variant", ctypes.c_int),
+        ("steps_per_launch", ctypes.c_int),
+    ]
+
+
+class Rng(ctypes.Structure):
+    _fields_ = [("r", ctypes.c_int32 * 34), ("pos", ctypes.c_int32)]
+
+
+# name -> (restype, argtypes): every symbol include/lorastencil.h declares
+SIGNATURES = {
+    "lora_shape_ntaps": (ctypes.c_int, [ctypes.c_int]),
+    "lora_shape_ndim": (ctypes.c_int, [ctypes.c_int]),
+    "lora_shape_from_name": (ctypes.c_int, [ctypes.c_char_p]),
+    "lora_shape_info_name": (ctypes.c_char_p, [ctypes.c_int]),
+    "lora_padded_count": (ctypes.c_size_t, [ctypes.c_int, _ip]),
+    "lora_shape_gstencil_factor": (ctypes.c_int, [ctypes.c_int]),
+    "lora_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "lora_last_error": (ctypes.c_char_p, []),
+    "lora_device_count": (ctypes.c_int, []),
+    "lora_gpu_1d1r": (ctypes.c_int, [_dp, _dp, _dp, ctypes.c_int, ctypes.c_int]),
+    "lora_gpu_1d2r": (ctypes.c_int, [_dp, _dp, _dp, ctypes.c_int, ctypes.c_int]),
+    "lora_gpu_star_2d1r": (ctypes.c_int, [_dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "lora_gpu_star_2d3r": (ctypes.c_int, [_dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "lora_gpu_box_2d3r": (ctypes.c_int, [_dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "lora_gpu_box_3d1r": (ctypes.c_int, [_dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "lora_gpu_star_3d1r": (ctypes.c_int, [_dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "lora_run_host": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _ip, ctypes.c_int,
+                                     ctypes.POINTER(RunInfo)]),
+    "lora_last_run_info": (ctypes.c_int, [ctypes.POINTER(RunInfo)]),
+    "lora_plan_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, _ip, _dp]),
+    "lora_plan_set_weights": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),
+    "lora_plan_get_weights": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),
+    "lora_plan_set_variant": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lora_plan_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
+    "lora_plan_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _ip]),
+    "lora_plan_padded_bytes": (ctypes.c_size_t, [_vp]),
+    "lora_plan_kernel_name": (ctypes.c_char_p, [_vp]),
+    "lora_plan_step": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "lora_plan_step_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "lora_plan_region_granularity": (ctypes.c_int, [_vp]),
+    "lora_plan_run": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),
+    "lora_plan_destroy": (None, [_vp]),
+    "lora_default_params": (ctypes.c_int, [ctypes.c_int, _dp]),
+    "lora_effective_weights": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
+    "lora_factorize_7x7": (ctypes.c_int, [_dp, _dp, _dp, _dp]),
+    "lora_rng_seed": (None, [ctypes.POINTER(Rng), ctypes.c_uint]),
+    "lora_rng_next": (ctypes.c_int, [ctypes.POINTER(Rng)]),
+    "lora_fill_rand": (None, [_dp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(Rng)]),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded engine; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP engine first (python -c 'import __graft_entry__ as g; "
+                f"g.build()' or make -C lorastencil_amd/csrc).  lorastencil_amd has no CPU fallback."
+            )
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(status: int, where: str) -> None:
+    if status != LORA_OK:
+        L = lib()
+        detail = L.lora_strerror(status).decode()
+        last = L.lora_last_error().decode()
+        raise LoraError(status, where, f"{detail}; {last}" if last else detail)

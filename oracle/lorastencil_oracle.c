@@ -283,15 +283,14 @@ void oracle_step_2d(const double *in, double *out, const double *w, int rows, in
     /* 2d/main.cu:38-93: rows/cols are the PADDED extents, halo 4, taps in row-major order */
     const int nt = pick_threads(threads);
     (void) nt;
+    ptrdiff_t off[49]; /* tap k = (dy, dx) in row-major order, as the reference writes the sum out */
+    for (int k = 0; k < 49; k++) off[k] = (k / 7 - 3) * (ptrdiff_t) cols + (k % 7 - 3);
 #pragma omp parallel for num_threads(nt) schedule(static) if (nt > 1)
     for (int row = 4; row < rows - 4; row++) {
         for (int col = 4; col < cols - 4; col++) {
             const double *c = in + (size_t) row * cols + col;
-            double s = w[0] * c[-3 * (ptrdiff_t) cols - 3];
-            for (int k = 1; k < 49; k++) {
-                const int dy = k / 7 - 3, dx = k % 7 - 3;
-                s = s + w[k] * c[dy * (ptrdiff_t) cols + dx];
-            }
+            double s = w[0] * c[off[0]];
+            for (int k = 1; k < 49; k++) s = s + w[k] * c[off[k]];
             out[(size_t) row * cols + col] = s;
         }
     }
@@ -302,16 +301,15 @@ void oracle_step_3d(const double *in, double *out, const double *w, int heights,
     const int nt = pick_threads(threads);
     (void) nt;
     const ptrdiff_t plane = (ptrdiff_t) rows * cols;
+    ptrdiff_t off[27]; /* tap k = (dz, dy, dx) in row-major order */
+    for (int k = 0; k < 27; k++) off[k] = (k / 9 - 1) * plane + ((k / 3) % 3 - 1) * (ptrdiff_t) cols + (k % 3 - 1);
 #pragma omp parallel for num_threads(nt) schedule(static) collapse(2) if (nt > 1)
     for (int h = 1; h < heights - 1; h++) {
         for (int row = 2; row < rows - 2; row++) {
             for (int col = 4; col < cols - 4; col++) {
                 const double *c = in + h * plane + (ptrdiff_t) row * cols + col;
-                double s = w[0] * c[-plane - cols - 1];
-                for (int k = 1; k < 27; k++) {
-                    const int dz = k / 9 - 1, dy = (k / 3) % 3 - 1, dx = k % 3 - 1;
-                    s = s + w[k] * c[dz * plane + dy * (ptrdiff_t) cols + dx];
-                }
+                double s = w[0] * c[off[0]];
+                for (int k = 1; k < 27; k++) s = s + w[k] * c[off[k]];
                 out[h * plane + (ptrdiff_t) row * cols + col] = s;
             }
         }

@@ -1,0 +1,140 @@
+"""CPU tests of the boundary: the C-ABI library loads, exports every symbol include/lorastencil.h declares, its
+host helpers agree with the oracle, argument validation works, and compute entry points fail loudly without a
+GPU (no fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+from conftest import ALL_SHAPES, ROOT, has_gpu, load_golden
+
+from oracle import oracle as O
+
+
+@pytest.fixture(scope="module")
+def L(engine_built):
+    import lorastencil_amd as L
+
+    return L
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "lorastencil.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lora_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(L):
+    import ctypes
+
+    from lorastencil_amd import _lib
+
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    names = declared_symbols()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/lorastencil.h but not exported"
+    # and the Python binding table covers the same set
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_shim_library_exports_reference_signatures(engine_built):
+    import subprocess
+
+    path = os.path.join(ROOT, "lorastencil_amd", "lib", "liblorastencil_shims.so")
+    syms = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    # Itanium manglings of the reference prototypes (1d_utils.h:45-47, 2d_utils.h:47-51, 3d_utils.h:44-48)
+    for m in ["_Z8gpu_1d1rPKdPdS0_ii", "_Z8gpu_1d2rPKdPdS0_ii", "_Z13gpu_star_2d1rPKdPdS0_iii",
+              "_Z13gpu_star_2d3rPKdPdS0_iii", "_Z12gpu_box_2d3rPKdPdS0_iii", "_Z12gpu_box_3d1rPKdPdS0_iiii",
+              "_Z13gpu_star_3d1rPKdPdS0_iiii"]:
+        assert m in syms, m
+
+
+@pytest.mark.parametrize("shape", ALL_SHAPES)
+def test_params_and_weights_match_oracle(L, shape):
+    assert np.array_equal(L.default_params(shape), O.default_params(shape))
+    assert np.array_equal(L.effective_weights(shape), O.effective_weights(shape))
+    rng = np.random.default_rng(7)
+    p = rng.standard_normal(O.NTAPS[O.NDIM[O.SHAPES[shape]]])
+    if shape.startswith("box2d"):
+        p = p.reshape(7, 7)
+        p = p + p.T + p[::-1] + p[:, ::-1]  # the pyramid factoriser assumes a symmetric matrix
+        p = (p + p[::-1, ::-1]).ravel()
+    assert np.array_equal(L.effective_weights(shape, p), O.effective_weights(shape, p))
+
+
+def test_factorizer_matches_oracle_and_reports_residual(L):
+    p = L.default_params("box2d3r")
+    u, v, res = L.factorize_7x7(p)
+    uo, vo = O.factorize_7x7(p)
+    assert np.array_equal(u, uo) and np.array_equal(v, vo) and res == 0.0
+    p2 = p.copy()
+    p2[24] = 10.0
+    u, v, res = L.factorize_7x7(p2)
+    uo, vo = O.factorize_7x7(p2)
+    assert np.array_equal(u, uo) and np.array_equal(v, vo) and res == 2.0
+    # reconstruction of the first three terms = what the operator applies
+    w = sum(np.outer(u[t], v[t]) for t in range(3))
+    assert np.array_equal(w.ravel(), L.effective_weights("box2d3r", p2))
+
+
+def test_glibc_rand_fill_matches_oracle_and_golden(L):
+    r = L.GlibcRand()
+    ro = O.Rng()
+    assert [r.next() for _ in range(1000)] == [ro.next() for _ in range(1000)]
+    for shape in ("1d1r", "star2d1r", "box3d1r"):
+        g = load_golden(shape)
+        assert np.array_equal(L.reference_input(shape, tuple(g["dims"])), g["input"])
+
+
+def test_shape_tables(L):
+    from lorastencil_amd import _lib
+
+    lib = _lib.lib()
+    info = [lib.lora_shape_info_name(s).decode() for s in range(8)]
+    assert info == ["1d1r", "1d2r", "star_2d1r", "box_2d1r", "star_2d3r", "box_2d3r", "star_3d1r", "box_3d1r"]
+    assert [lib.lora_shape_gstencil_factor(s) for s in range(8)] == [3, 2, 3, 3, 1, 3, 1, 1]
+    assert lib.lora_shape_from_name(b"star2d1r") == 2 and lib.lora_shape_from_name(b"nope") < 0
+    assert L.padded_shape("star3d1r", (512, 512, 512)) == (514, 516, 520)
+
+
+def test_plan_validation(L):
+    with pytest.raises(L.LoraError):
+        L.Plan("star2d1r", (64, 127))  # odd innermost extent: rejected, not mis-computed
+    with pytest.raises(L.LoraError):
+        L.Plan("star2d1r", (0, 128))
+    p = L.Plan("star2d1r", (64, 128))
+    assert p.get_option("tapset") == 0  # 25-tap diamond
+    assert L.Plan("star2d3r", (64, 128)).get_option("tapset") == 1
+    assert L.Plan("box2d3r", (64, 128)).get_option("tapset") == 2
+    assert L.Plan("star3d1r", (8, 16, 128)).get_option("tapset") == 0
+    assert L.Plan("box3d1r", (8, 16, 128)).get_option("tapset") == 1
+    p.set_weights(np.ones(49))
+    assert p.get_option("tapset") == 2
+    with pytest.raises(L.LoraError):
+        p.set_weights(np.ones(9))
+    with pytest.raises(L.LoraError):
+        p.set_option("rows_per_thread", 5)
+    with pytest.raises(L.LoraError):
+        p.step(0, 0)  # null buffers
+
+
+@pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
+def test_compute_fails_loudly_without_gpu(L):
+    from lorastencil_amd import _lib
+
+    a = L.reference_input("star2d1r", (32, 64))
+    with pytest.raises(L.LoraError) as e:
+        L.run_host("star2d1r", a, times=1)
+    assert e.value.status == _lib.LORA_ENODEVICE
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under lorastencil_amd/ may import, load or link it."""
+    pkg = os.path.join(ROOT, "lorastencil_amd")
+    pat = re.compile(r"(from\s+oracle|import\s+oracle|liblorastencil_oracle|oracle/|lorastencil_oracle\.h|-loracle)")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f)).read()
+                assert not pat.search(text), f"{os.path.join(dirpath, f)} reaches into oracle/"

@@ -1,0 +1,119 @@
+"""CPU tests of the oracle itself: pinned to libc rand(), to the golden fixtures generated from the reference's
+own test_cpu, and (when oracle/_ref is present) to that test_cpu directly."""
+import ctypes
+
+import numpy as np
+import pytest
+from conftest import ALL_SHAPES, load_golden
+
+from oracle import oracle as o
+from oracle import ref
+
+
+def test_rng_matches_libc_rand():
+    libc = ctypes.CDLL("libc.so.6")
+    r = o.Rng()
+    assert [r.next() for _ in range(5000)] == [libc.rand() for _ in range(5000)]
+
+
+def test_rng_first_values_known_answer():
+    # glibc rand() with the default seed: the first outputs are a well known sequence
+    r = o.Rng()
+    assert [r.next() for _ in range(3)] == [1804289383, 846930886, 1681692777]
+
+
+@pytest.mark.parametrize("shape", ALL_SHAPES)
+def test_fill_matches_golden_input(shape):
+    g = load_golden(shape)
+    a = o.reference_input(shape, tuple(g["dims"]))
+    assert np.array_equal(a, g["input"])
+    assert np.array_equal(o.default_params(shape), g["params"])
+
+
+@pytest.mark.parametrize("shape", ALL_SHAPES)
+@pytest.mark.parametrize("t", [1, 2, 3, 4])
+def test_oracle_matches_golden_bit_exact(shape, t):
+    g = load_golden(shape)
+    out = o.run(shape, g["input"], t)
+    exp = g[f"out_t{t}"]
+    if out.ndim == 1:  # the operator leaves the last element of `out` untouched (1d/gpu_1r.cu:134)
+        assert np.array_equal(out[:-1], exp[:-1])
+        assert out[-1] == 0.0
+    else:
+        assert np.array_equal(out, exp)
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("shape,dims", [("1d1r", (96,)), ("star2d1r", (16, 32)), ("box2d3r", (8, 24)),
+                                        ("star2d3r", (12, 20)), ("star3d1r", (5, 6, 18)), ("box3d1r", (4, 9, 10))])
+def test_oracle_step_equals_reference_test_cpu_random_params(shape, dims):
+    rng = np.random.default_rng(42)
+    a = rng.standard_normal(o.padded_shape(shape, dims))
+    p = rng.standard_normal(o.NTAPS[len(dims)])
+    assert np.array_equal(o.interior(shape, ref.test_cpu(a, p)), o.interior(shape, o.step(shape, a, p)))
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("shape", ALL_SHAPES)
+def test_oracle_driver_equals_reference_chain(shape):
+    g = load_golden(shape)
+    for t in (0, 5, 6):
+        exp = ref.run_chain(g["input"], g["params"], t)
+        out = o.run(shape, g["input"], t)
+        n = -1 if out.ndim == 1 else None
+        assert np.array_equal(out.ravel()[:n], exp.ravel()[:n])
+
+
+def test_effective_weights_of_reference_tables():
+    # for the reference's own tables the applied taps equal the table
+    for s in ALL_SHAPES:
+        assert np.array_equal(o.effective_weights(s), o.default_params(s)), s
+
+
+def test_effective_weights_ignore_what_the_reference_ignores():
+    rng = np.random.default_rng(1)
+    junk49, junk27 = rng.standard_normal(49), rng.standard_normal(27)
+    assert np.array_equal(o.effective_weights("star2d1r", junk49), o.default_params("star2d1r"))
+    assert np.array_equal(o.effective_weights("star3d1r", junk27), o.default_params("star3d1r"))
+    w = o.effective_weights("box3d1r", junk27).reshape(3, 3, 3)
+    assert np.array_equal(w, np.broadcast_to(junk27[:3], (3, 3, 3)))
+    w = o.effective_weights("star2d3r", junk49).reshape(7, 7)
+    p = junk49.reshape(7, 7)
+    assert np.array_equal(w[:, 3], p[:, 3]) and np.array_equal(np.delete(w[3], 3), np.delete(p[3], 3))
+    off = np.ones((7, 7), bool)
+    off[3, :] = off[:, 3] = False
+    assert not w[off].any()
+
+
+def test_factorizer_reference_table():
+    u, v = o.factorize_7x7(o.default_params("box2d3r"))
+    assert u[0].tolist() == [1, 2, 3, 4, 3, 2, 1] and v[0].tolist() == [1, 2, 3, 4, 3, 2, 1]
+    assert u[1].tolist() == [0, 1, 0, -1, 0, 1, 0] and v[1].tolist() == [0, 1, 0, -1, 0, 1, 0]
+    assert u[2].tolist() == [0, 0, -1, -3, -1, 0, 0] and v[2].tolist() == [0, 0, 1, 3, 1, 0, 0]
+    assert v[3][3] == 0.0  # the dropped fourth term vanishes for the reference table only
+
+
+def test_factorizer_drops_fourth_term():
+    p = o.default_params("box2d3r").copy()
+    p[24] = 10.0  # the loop's own centre value (2d/main.cu:149-166) makes the matrix rank 4
+    w = o.effective_weights("box2d3r", p).reshape(7, 7)
+    assert w[3, 3] == 8.0  # the operator still applies the rank-3 part only (2d/gpu.cu:358-369)
+    u, v = o.factorize_7x7(p)
+    assert v[3][3] == 2.0
+
+
+def test_halo_alternation_and_parity():
+    g = load_golden("star2d1r")
+    a = g["input"]
+    out1 = o.run("star2d1r", a, 1)
+    out2 = o.run("star2d1r", a, 2)
+    halo = np.ones(a.shape, bool)
+    halo[4:-4, 4:-4] = False
+    assert not out1[halo].any()                  # odd step count: buffer 1, halo = 0
+    assert np.array_equal(out2[halo], a[halo])   # even: buffer 0, halo = the caller's input halo
+    assert np.array_equal(o.run("star2d1r", a, 0), a)
+
+
+def test_threads_do_not_change_results():
+    g = load_golden("box3d1r")
+    assert np.array_equal(o.run("box3d1r", g["input"], 3, threads=1), o.run("box3d1r", g["input"], 3, threads=4))
