@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -47,6 +48,80 @@ int region_granularity(const Plan &p) {
     }
 }
 
+// Factors for the MFMA formulation out = sum_t (U_t X) V_t + residual taps, derived from the applied taps W:
+//   * c x the star2d1r table  -> the reference's hard-coded rank-1 factor u = v = (0,1,2,4,2,1,0) plus its 8-point
+//                                correction (2d/gpu.cu:486-487, :249-264), scaled by c;
+//   * star-shaped W           -> vertical band = centre column, horizontal band = centre row without the centre
+//                                (2d/gpu.cu:433-444), i.e. two terms with a unit factor each;
+//   * anything else           -> pyramid factorisation into three terms (2d/gpu.cu:280-350); what it does not
+//                                capture is applied as residual taps if it is sparse enough.
+static void derive_lowrank(Plan &p) {
+    LowRank2D &lr = p.lowrank;
+    lr = LowRank2D{};
+    p.lowrank_valid = false;
+    if (p.ndim != 2) return;
+    const double *W = p.w;
+    auto finish_residual = [&](double tol) {
+        double wmax = 0.0;
+        for (int k = 0; k < 49; ++k) wmax = std::fmax(wmax, std::fabs(W[k]));
+        lr.nresid = 0;
+        for (int r = 0; r < 7; ++r)
+            for (int c = 0; c < 7; ++c) {
+                double s = 0.0;
+                for (int t = 0; t < lr.rank; ++t) s += lr.u[t][r] * lr.v[t][c];
+                const double d = W[r * 7 + c] - s;
+                if (!std::isfinite(d)) return false;
+                if (std::fabs(d) > tol * wmax) {
+                    if (lr.nresid == 16) return false;
+                    lr.rdy[lr.nresid] = r - 3;
+                    lr.rdx[lr.nresid] = c - 3;
+                    lr.rw[lr.nresid] = d;
+                    ++lr.nresid;
+                }
+            }
+        return true;
+    };
+    // (1) scaled star2d1r table
+    double ref[49];
+    default_params(LORA_STAR2D1R, ref);
+    const double c = W[24] / ref[24];
+    bool scaled = std::isfinite(c) && c != 0.0;
+    for (int k = 0; k < 49 && scaled; ++k) scaled = std::fabs(W[k] - c * ref[k]) <= 1e-14 * std::fabs(c * ref[24]);
+    if (scaled) {
+        static const double f[7] = {0, 1, 2, 4, 2, 1, 0};
+        lr.rank = 1;
+        for (int e = 0; e < 7; ++e) {
+            lr.u[0][e] = c * f[e];
+            lr.v[0][e] = f[e];
+        }
+        p.lowrank_valid = finish_residual(1e-14);
+        return;
+    }
+    // (2) star-shaped taps
+    if (p.tapset == TAPS2D_STAR) {
+        lr.rank = 2;
+        for (int e = 0; e < 7; ++e) {
+            lr.u[0][e] = W[e * 7 + 3];
+            lr.v[0][e] = (e == 3) ? 1.0 : 0.0;
+            lr.u[1][e] = (e == 3) ? 1.0 : 0.0;
+            lr.v[1][e] = (e == 3) ? 0.0 : W[3 * 7 + e];
+        }
+        p.lowrank_valid = finish_residual(1e-14);
+        return;
+    }
+    // (3) pyramid factorisation
+    double u[4][7], v[4][7];
+    factorize_7x7(W, u, v, nullptr);
+    lr.rank = 3;
+    for (int t = 0; t < 3; ++t)
+        for (int e = 0; e < 7; ++e) {
+            if (!std::isfinite(u[t][e]) || !std::isfinite(v[t][e])) return;
+            lr.u[t][e] = u[t][e];
+            lr.v[t][e] = v[t][e];
+        }
+    p.lowrank_valid = finish_residual(1e-13);
+}
+
 void plan_refresh(Plan &p) {
     if (p.ndim == 2) {
         // smallest tap set that covers the non-zero pattern of the applied taps
@@ -59,6 +134,8 @@ void plan_refresh(Plan &p) {
                 if (ar + ac > 3) diamond = false;
             }
         p.tapset = star ? TAPS2D_STAR : (diamond ? TAPS2D_DIAMOND : TAPS2D_BOX);
+        derive_lowrank(p);
+        if (p.variant == LORA_VARIANT_MFMA && !p.lowrank_valid) p.variant = LORA_VARIANT_DIRECT;
         p.kernel_name = (p.variant == LORA_VARIANT_MFMA) ? kernel_name_2d_mfma(p) : kernel_name_2d_direct(p);
     } else if (p.ndim == 3) {
         bool star = true;
@@ -205,6 +282,10 @@ int lora_plan_set_variant(lora_plan *plan, int variant) {
     if (variant == LORA_VARIANT_AUTO) variant = LORA_VARIANT_DIRECT;
     if (variant == LORA_VARIANT_MFMA && plan->p.ndim != 2) return LORA_EUNSUPPORTED;
     if (variant != LORA_VARIANT_DIRECT && variant != LORA_VARIANT_MFMA) return LORA_EINVAL;
+    if (variant == LORA_VARIANT_MFMA && !plan->p.lowrank_valid) {
+        g_last_error = "these taps have no rank<=3 + sparse-residual factorisation";
+        return LORA_EUNSUPPORTED;
+    }
     plan->p.variant = variant;
     lora::plan_refresh(plan->p);
     return LORA_OK;
@@ -222,6 +303,8 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "z_chunk")) {
         if (value < 1) return LORA_EINVAL;
         p.z_chunk = value;
+    } else if (!std::strcmp(key, "nt_store")) {
+        p.nt_store = value ? 1 : 0;
     } else if (!std::strcmp(key, "steps_per_launch")) {
         if (value != 1) return LORA_EUNSUPPORTED;
         p.steps_per_launch = value;
@@ -241,6 +324,8 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.panel_width;
     else if (!std::strcmp(key, "z_chunk"))
         *value = p.z_chunk;
+    else if (!std::strcmp(key, "nt_store"))
+        *value = p.nt_store;
     else if (!std::strcmp(key, "steps_per_launch"))
         *value = p.steps_per_launch;
     else if (!std::strcmp(key, "tapset"))

@@ -51,7 +51,8 @@ struct Plan {
     int tapset = 0;
     // tuning knobs (lora_plan_set_option)
     int rows_per_thread = 8;  // 2D direct: output rows per lane (tile height = 4x this)
-    int panel_width = 8;      // 2D: tile columns per L2 panel of the block->tile map
+    int panel_width = 32;     // 2D: tile columns per L2 panel of the block->tile map
+    int nt_store = 0;         // 2D: non-temporal output stores
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
     int steps_per_launch = 1;
     bool lowrank_valid = false;

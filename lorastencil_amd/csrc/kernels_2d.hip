@@ -79,7 +79,7 @@ struct Args2D {
     int panel_w;
 };
 
-template <int TAPSET, int RPT>
+template <int TAPSET, int RPT, bool NT>
 __global__ __launch_bounds__(256, (RPT <= 4 ? 6 : (RPT <= 8 ? 3 : 2))) void stencil2d_direct_kernel(const Args2D a, const Taps49 W) {
     constexpr int TH = 4 * RPT;
     constexpr int LH = TH + 6;
@@ -176,7 +176,11 @@ __global__ __launch_bounds__(256, (RPT <= 4 ? 6 : (RPT <= 8 ? 3 : 2))) void sten
                 d2 v;
                 v.x = acc0[r];
                 v.y = acc1[r];
-                *reinterpret_cast<d2 *>(a.out + (size_t) (row + 4) * a.ld + (col + 4)) = v;
+                d2 *dstp = reinterpret_cast<d2 *>(a.out + (size_t) (row + 4) * a.ld + (col + 4));
+                if (NT)
+                    __builtin_nontemporal_store(v, dstp);  // written once, read next launch: keep L2 for the halos
+                else
+                    *dstp = v;
             }
         }
 #pragma unroll
@@ -185,7 +189,7 @@ __global__ __launch_bounds__(256, (RPT <= 4 ? 6 : (RPT <= 8 ? 3 : 2))) void sten
     }
 }
 
-template <int TAPSET, int RPT>
+template <int TAPSET, int RPT, bool NT>
 hipError_t launch_direct(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
     constexpr int TH = 4 * RPT;
     Args2D a;
@@ -204,19 +208,29 @@ hipError_t launch_direct(const Plan &p, const double *in, double *out, int begin
     const long nblocks = (long) a.tiles_x * a.tiles_y;
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((stencil2d_direct_kernel<TAPSET, RPT>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
+    hipLaunchKernelGGL((stencil2d_direct_kernel<TAPSET, RPT, NT>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
     return hipGetLastError();
 }
 
 template <int TAPSET>
 hipError_t launch_direct_rpt(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
+    if (p.nt_store) {
+        switch (p.rows_per_thread) {
+            case 4:
+                return launch_direct<TAPSET, 4, true>(p, in, out, begin, end, s);
+            case 16:
+                return launch_direct<TAPSET, 16, true>(p, in, out, begin, end, s);
+            default:
+                return launch_direct<TAPSET, 8, true>(p, in, out, begin, end, s);
+        }
+    }
     switch (p.rows_per_thread) {
         case 4:
-            return launch_direct<TAPSET, 4>(p, in, out, begin, end, s);
+            return launch_direct<TAPSET, 4, false>(p, in, out, begin, end, s);
         case 16:
-            return launch_direct<TAPSET, 16>(p, in, out, begin, end, s);
+            return launch_direct<TAPSET, 16, false>(p, in, out, begin, end, s);
         default:
-            return launch_direct<TAPSET, 8>(p, in, out, begin, end, s);
+            return launch_direct<TAPSET, 8, false>(p, in, out, begin, end, s);
     }
 }
 

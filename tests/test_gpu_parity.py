@@ -59,6 +59,24 @@ def plan_run(L, shape, a, times, weights=None, options=None, params=None):
     return (b0, b1)[times % 2].cpu().numpy()
 
 
+def plan_run_variant(L, shape, a, times, variant, weights=None):
+    import torch
+
+    h = L.ops.halo(shape)
+    dims = tuple(a.shape[i] - 2 * h[i] for i in range(a.ndim))
+    plan = L.Plan(shape, dims)
+    if weights is not None:
+        plan.set_weights(weights)
+    plan.set_variant(variant)
+    assert plan.get_option("variant") == variant
+    assert "mfma" in plan.kernel_name or variant != L.VARIANT_MFMA
+    b0 = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    b1 = torch.zeros_like(b0)
+    plan.run(b0, b1, times)
+    torch.cuda.synchronize()
+    return (b0, b1)[times % 2].cpu().numpy()
+
+
 # ---------------------------------------------------------------------------------------------------------
 # golden fixtures (reference test_cpu) through both C-ABI groups
 # ---------------------------------------------------------------------------------------------------------
@@ -133,6 +151,38 @@ def test_2d_kernel_options_do_not_change_results(L, O, rpt, panel):
     exp = O.run(shape, a, 2)
     got = plan_run(L, shape, a, 2, options={"rows_per_thread": rpt, "panel_width": panel})
     assert np.array_equal(got, exp)
+
+
+@pytest.mark.parametrize("shape", ["star2d1r", "box2d3r", "box2d1r", "star2d3r"])
+def test_mfma_lowrank_variant_matches_golden_and_oracle(L, O, shape):
+    """The low-rank (U X) V formulation on v_mfma_f64_16x16x4 (kernels_2d_mfma.hip) against the same fixtures."""
+    g = load_golden(shape)
+    dims = tuple(int(d) for d in g["dims"])
+    for t in (1, 2, 4):
+        got = plan_run_variant(L, shape, g["input"], t, L.VARIANT_MFMA)
+        assert np.array_equal(got, g[f"out_t{t}"]), f"{shape} t={t}"
+    for dims in ((40, 130), (96, 384), (1, 2)):  # ragged tiles
+        a = O.reference_input(shape, dims)
+        assert np.array_equal(plan_run_variant(L, shape, a, 3, L.VARIANT_MFMA), O.run(shape, a, 3)), dims
+
+
+def test_mfma_variant_real_weights_and_scaling(L, O):
+    rng = np.random.default_rng(9)
+    a = rng.standard_normal(O.padded_shape("star2d1r", (64, 256)))
+    # normalised star2d1r taps (a scaled copy of the reference table keeps its rank-1 + correction form)
+    w = O.effective_weights("star2d1r") / 100.0
+    got = plan_run_variant(L, "star2d1r", a, 5, L.VARIANT_MFMA, weights=w)
+    assert rel_err(got, O.run("star2d1r", a, 5, weights=w)) < 1e-13
+    # a symmetric box table with a non-vanishing 4th pyramid term: the residual goes to the vector pipe
+    p = O.default_params("box2d3r").copy()
+    p[24] = 10.0
+    got = plan_run_variant(L, "box2d3r", a, 2, L.VARIANT_MFMA, weights=p / p.sum())
+    assert rel_err(got, O.run("box2d3r", a, 2, weights=p / p.sum())) < 1e-13
+    # taps with no low-rank form are refused, not mis-computed
+    plan = L.Plan("box2d3r", (64, 256))
+    plan.set_weights(rng.standard_normal(49))
+    with pytest.raises(L.LoraError):
+        plan.set_variant(L.VARIANT_MFMA)
 
 
 @pytest.mark.parametrize("zc", [1, 2, 4, 7, 16, 40])

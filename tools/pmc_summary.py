@@ -1,0 +1,86 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output directories (gpurun_out/prof_*) into the small, committed files under profiles/:
+
+  profiles/<tag>_kernel_stats.csv     the --stats per-kernel table (kernel names shortened)
+  profiles/<tag>_pmc.json             per-kernel means of every collected counter, with the gfx950 corrections of
+                                      MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB,
+                                      FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane streaming reads (x2)
+  profiles/pmc_traffic.json           HBM bytes per launch of the dominant kernel, keyed "<shape>:<dims>:<gpus>",
+                                      which bench.py reports as roofline.traffic
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void ", "", name)
+    return name.split("(")[0][:80]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--stats", default=None, help="directory of a --kernel-trace --stats run")
+    ap.add_argument("--pmc", nargs="*", default=[], help="directories of --pmc runs")
+    ap.add_argument("--kernel", default="stencil", help="substring of the kernels of interest")
+    ap.add_argument("--traffic-key", default=None, help='e.g. "star2d1r:16384x16384:1"')
+    args = ap.parse_args()
+    prof = os.path.join(ROOT, "profiles")
+    os.makedirs(prof, exist_ok=True)
+
+    if args.stats:
+        f = glob.glob(os.path.join(args.stats, "**", "*_kernel_stats.csv"), recursive=True)[0]
+        rows = list(csv.DictReader(open(f)))
+        out = os.path.join(prof, f"{args.tag}_kernel_stats.csv")
+        with open(out, "w", newline="") as fo:
+            w = csv.writer(fo)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"],
+                            r["MinNs"], r["MaxNs"], r["StdDev"]])
+        print("wrote", out)
+
+    counters = collections.defaultdict(lambda: collections.defaultdict(list))
+    durations = collections.defaultdict(list)
+    for d in args.pmc:
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                if args.kernel in r["Kernel_Name"]:
+                    k = short(r["Kernel_Name"])
+                    counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    durations[k].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    if counters:
+        summary = {}
+        for k, cs in counters.items():
+            e = {c: {"mean": sum(v) / len(v), "n": len(v)} for c, v in cs.items()}
+            e["_mean_duration_ns_under_pmc"] = sum(durations[k]) / len(durations[k])
+            if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                fetch = e["FETCH_SIZE"]["mean"] * 1024 * 2  # KiB, x2: gfx950 wide-read correction
+                write = e["WRITE_SIZE"]["mean"] * 1024
+                e["hbm_read_bytes_per_launch"] = fetch
+                e["hbm_write_bytes_per_launch"] = write
+                e["hbm_bytes_per_launch"] = fetch + write
+            summary[k] = e
+        out = os.path.join(prof, f"{args.tag}_pmc.json")
+        json.dump(summary, open(out, "w"), indent=1, sort_keys=True)
+        print("wrote", out)
+        if args.traffic_key:
+            tpath = os.path.join(prof, "pmc_traffic.json")
+            t = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            best = max(summary.values(), key=lambda e: e.get("hbm_bytes_per_launch", 0))
+            if "hbm_bytes_per_launch" in best:
+                t[args.traffic_key] = round(best["hbm_bytes_per_launch"])
+                json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
+                print("traffic", args.traffic_key, t[args.traffic_key])
+
+
+if __name__ == "__main__":
+    main()

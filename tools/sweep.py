@@ -52,9 +52,12 @@ def main():
     del a, b
 
     cases = [
-        ("star2d1r", (16384, 16384), {"rows_per_thread": [4, 8, 16], "panel_width": [1, 4, 8, 16, 128]}),
-        ("box2d3r", (8192, 8192), {"rows_per_thread": [4, 8, 16], "panel_width": [8]}),
-        ("star2d3r", (16384, 16384), {"rows_per_thread": [4, 8, 16], "panel_width": [8]}),
+        ("star2d1r", (16384, 16384), {"rows_per_thread": [4, 8], "panel_width": [16, 32], "variant": [1]}),
+        ("star2d1r", (16384, 16384), {"panel_width": [16, 32], "variant": [2]}),
+        ("box2d3r", (8192, 8192), {"rows_per_thread": [4, 8], "panel_width": [8, 16, 32, 64], "variant": [1]}),
+        ("box2d3r", (8192, 8192), {"panel_width": [16, 32], "variant": [2]}),
+        ("star2d3r", (16384, 16384), {"rows_per_thread": [4, 8], "panel_width": [16, 32], "variant": [1]}),
+        ("star2d3r", (16384, 16384), {"panel_width": [32], "variant": [2]}),
         ("star3d1r", (512, 512, 512), {"z_chunk": [4, 7, 16, 31, 64]}),
         ("box3d1r", (768, 768, 768), {"z_chunk": [7, 16, 31]}),
         ("star3d1r", (64, 512, 512), {"z_chunk": [4, 7, 16]}),
@@ -77,7 +80,10 @@ def main():
         combos = list(itertools.product(*[grid[k] for k in keys])) or [()]
         for combo in combos:
             for k, v in zip(keys, combo):
-                plan.set_option(k, v)
+                if k == "variant":
+                    plan.set_variant(v)
+                else:
+                    plan.set_option(k, v)
             iters = 5 if args.quick else 20
             t = time_fn(lambda: plan.step(src, dst), iters)
             record(kind="sweep", shape=shape, dims=dims, options=dict(zip(keys, combo)), kernel=plan.kernel_name,
