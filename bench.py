@@ -179,6 +179,7 @@ def main():
             plan.set_option(k, int(v))
         src0 = torch.randint(0, 100, drv.local_padded_shape, generator=gen, device=dev).to(torch.float64)
         run = lambda n: drv.run(n)  # noqa: E731
+        plan.set_option("steps_per_launch", 1) if len(dims) == 2 else None
         kernel = plan.kernel_name
         local_points = 1
         for d in drv.layout.local_dims:
@@ -215,13 +216,17 @@ def main():
     for d in dims:
         points *= d
     value = points * K / elapsed / 1e9
-    launch_s = ev_ms / 1e3 / K  # average duration of one sweep launch on the launch stream (HIP events)
-    achieved = local_points * 16.0 / launch_s / 1e9
+    # one launch applies `spl` sweeps (temporal fusion); algorithmic bytes stay 2 x 8 B per point per APPLICATION
+    spl = plan.get_option("steps_per_launch") if (len(dims) == 2 and world == 1) else 1  # slabs sweep one step per launch
+    launches = max(1, K // spl) if spl > 1 else K
+    launch_s = ev_ms / 1e3 / launches  # average launch duration on the launch stream (HIP events)
+    bytes_per_launch = local_points * 16.0 * (K / launches)
+    achieved = bytes_per_launch / launch_s / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"{shape}:{'x'.join(map(str, dims))}:{world}")
+            traffic = json.load(open(tpath)).get(f"{shape}:{'x'.join(map(str, dims))}:{world}:{kernel}")
         except Exception:
             traffic = None
 
@@ -246,6 +251,7 @@ def main():
                 "kernel": kernel,
                 "variant": {1: "direct", 2: "mfma"}.get(plan.get_option("variant"), "?"),
                 "normalised_taps": bool(normalised),
+                "steps_per_launch": spl,
             },
             "value_reference_convention": round(value * L.ops.gstencil_factor(shape), 3),
             "roofline": {
@@ -256,7 +262,8 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
                 "launch_us": round(launch_s * 1e6, 2),
-                "bytes_per_launch": local_points * 16,
+                "bytes_per_launch": round(bytes_per_launch),
+                "applications_per_launch": spl,
             },
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -158,6 +158,12 @@ int lora_plan_step(lora_plan *plan, const void *d_in, void *d_out, void *stream)
  * with the rest.  begin must be a multiple of lora_plan_region_granularity() (2 in 1D, 1 otherwise). */
 int lora_plan_step_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream);
 int lora_plan_region_granularity(const lora_plan *plan);
+/* TWO kernel applications in one launch (temporal fusion; 2D shapes, direct variant): the intermediate time level
+ * lives in LDS and its halo cells are taken as 0 -- the state of the reference driver's second buffer --
+ * so d_in must be an even time level (halo = the caller's input halo).  Interior of d_out <- stencil(stencil(d_in)).
+ * lora_plan_run uses it when the option "steps_per_launch" is 2. */
+int lora_plan_step2(lora_plan *plan, const void *d_in, void *d_out, void *stream);
+int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream);
 /* The time-step driver (2d/gpu.cu:544-546): `times` applications ping-ponging between the two
  * buffers starting from d_buf0; the result is in buffer [times % 2].  The caller must have put
  * the padded input in d_buf0 and zeros in d_buf1 to get the reference semantics. */

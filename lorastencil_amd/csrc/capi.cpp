@@ -136,7 +136,17 @@ void plan_refresh(Plan &p) {
         p.tapset = star ? TAPS2D_STAR : (diamond ? TAPS2D_DIAMOND : TAPS2D_BOX);
         derive_lowrank(p);
         if (p.variant == LORA_VARIANT_MFMA && !p.lowrank_valid) p.variant = LORA_VARIANT_DIRECT;
-        p.kernel_name = (p.variant == LORA_VARIANT_MFMA) ? kernel_name_2d_mfma(p) : kernel_name_2d_direct(p);
+        // temporal fusion pays where the sweep is HBM-bound (25- and 13-tap sets: 554 / 625 vs 352 / 345 GStencils/s
+        // on 16384^2, profiles/); the 49-tap box is FMA-bound either way (337 vs 350) and stays single-sweep
+        if (p.variant == LORA_VARIANT_MFMA)
+            p.steps_per_launch = 1;
+        else if (p.steps_per_launch_req == 0)
+            p.steps_per_launch = (p.tapset == TAPS2D_BOX) ? 1 : 2;
+        else
+            p.steps_per_launch = p.steps_per_launch_req;
+        p.kernel_name = (p.variant == LORA_VARIANT_MFMA)
+                            ? kernel_name_2d_mfma(p)
+                            : (p.steps_per_launch == 2 ? kernel_name_2d_fused2(p) : kernel_name_2d_direct(p));
     } else if (p.ndim == 3) {
         bool star = true;
         for (int k = 0; k < 27; ++k) {
@@ -152,7 +162,7 @@ void plan_refresh(Plan &p) {
     }
 }
 
-static int check_buffers(const void *a, const void *b) {
+int check_buffers(const void *a, const void *b) {
     if (!a || !b) return LORA_EINVAL;
     if ((reinterpret_cast<uintptr_t>(a) & 15) || (reinterpret_cast<uintptr_t>(b) & 15)) {
         g_last_error = "device buffers must be 16-byte aligned";
@@ -305,9 +315,13 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         p.z_chunk = value;
     } else if (!std::strcmp(key, "nt_store")) {
         p.nt_store = value ? 1 : 0;
+    } else if (!std::strcmp(key, "persistent")) {
+        p.persistent = value ? 1 : 0;
     } else if (!std::strcmp(key, "steps_per_launch")) {
-        if (value != 1) return LORA_EUNSUPPORTED;
-        p.steps_per_launch = value;
+        if (value < 0 || value > 2) return LORA_EINVAL;
+        if (value == 2 && (p.ndim != 2 || p.variant != LORA_VARIANT_DIRECT)) return LORA_EUNSUPPORTED;
+        p.steps_per_launch_req = value;
+        if (p.ndim != 2) p.steps_per_launch = 1;
     } else {
         return LORA_EINVAL;
     }
@@ -326,6 +340,8 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.z_chunk;
     else if (!std::strcmp(key, "nt_store"))
         *value = p.nt_store;
+    else if (!std::strcmp(key, "persistent"))
+        *value = p.persistent;
     else if (!std::strcmp(key, "steps_per_launch"))
         *value = p.steps_per_launch;
     else if (!std::strcmp(key, "tapset"))
@@ -356,10 +372,56 @@ int lora_plan_step(lora_plan *plan, const void *d_in, void *d_out, void *stream)
     return lora::step_region(plan->p, d_in, d_out, 0, plan->p.dims[0], static_cast<hipStream_t>(stream));
 }
 
+int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream) {
+    if (!plan) return LORA_EINVAL;
+    Plan &p = plan->p;
+    if (p.ndim != 2 || p.variant != LORA_VARIANT_DIRECT) return LORA_EUNSUPPORTED;
+    if (int rc = lora::check_buffers(d_in, d_out)) return rc;
+    if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
+    const hipError_t e = lora::launch_2d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),
+                                                begin, end, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        lora::set_last_error("fused kernel launch", e);
+        return LORA_EHIP;
+    }
+    return LORA_OK;
+}
+
+int lora_plan_step2(lora_plan *plan, const void *d_in, void *d_out, void *stream) {
+    if (!plan) return LORA_EINVAL;
+    return lora_plan_step2_region(plan, d_in, d_out, 0, plan->p.dims[0], stream);
+}
+
 int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream) {
     if (!plan || times < 0) return LORA_EINVAL;
+    Plan &p = plan->p;
     void *buf[2] = {d_buf0, d_buf1};
-    for (int i = 0; i < times; ++i) {  // 2d/gpu.cu:544-546
+    int done = 0;
+    if (p.steps_per_launch == 2 && p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && times >= 4) {
+        // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes the other one,
+        // so while fused launches run BOTH physical buffers carry buffer 0's halo; an even number of them leaves
+        // the data in buffer 0, after which buffer 1's halo is put back to 0 and the remaining 0..3 steps are
+        // single sweeps -- the result and its halo end up exactly where the step-by-step driver leaves them.
+        if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const int pairs = (times / 2) & ~1;
+        hipError_t e = lora::launch_halo_ring_2d(p, static_cast<double *>(d_buf1), static_cast<const double *>(d_buf0), s);
+        if (e != hipSuccess) {
+            lora::set_last_error("halo copy", e);
+            return LORA_EHIP;
+        }
+        for (int k = 0; k < pairs; ++k) {
+            const int rc = lora_plan_step2(plan, buf[k % 2], buf[(k + 1) % 2], stream);
+            if (rc != LORA_OK) return rc;
+        }
+        e = lora::launch_halo_ring_2d(p, static_cast<double *>(d_buf1), nullptr, s);
+        if (e != hipSuccess) {
+            lora::set_last_error("halo reset", e);
+            return LORA_EHIP;
+        }
+        done = 2 * pairs;
+    }
+    for (int i = done; i < times; ++i) {  // 2d/gpu.cu:544-546
         const int rc = lora_plan_step(plan, buf[i % 2], buf[(i + 1) % 2], stream);
         if (rc != LORA_OK) return rc;
     }

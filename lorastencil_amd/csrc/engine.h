@@ -53,8 +53,10 @@ struct Plan {
     int rows_per_thread = 8;  // 2D direct: output rows per lane (tile height = 4x this)
     int panel_width = 32;     // 2D: tile columns per L2 panel of the block->tile map
     int nt_store = 0;         // 2D: non-temporal output stores
+    int persistent = 0;       // 2D fused: persistent workgroups with register prefetch of the next tile
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
-    int steps_per_launch = 1;
+    int steps_per_launch_req = 0;  // 0 = auto (fused for the diamond / star tap sets), 1, 2
+    int steps_per_launch = 1;      // resolved
     bool lowrank_valid = false;
     LowRank2D lowrank{};
     std::string kernel_name;
@@ -67,6 +69,11 @@ void plan_refresh(Plan &p);  // re-derive tapset / low-rank factors / kernel nam
 hipError_t launch_1d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 hipError_t launch_2d_direct(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 hipError_t launch_2d_mfma(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+// two applications per launch (intermediate level in LDS, its halo = 0); 2D direct taps only
+hipError_t launch_2d_fused2(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+// halo ring of a padded 2D array: dst <- src, or dst <- 0 when src == nullptr
+hipError_t launch_halo_ring_2d(const Plan &p, double *dst, const double *src, hipStream_t s);
+const char *kernel_name_2d_fused2(const Plan &p);
 hipError_t launch_3d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 
 const char *kernel_name_1d(const Plan &p);

@@ -283,6 +283,14 @@ class Plan:
         check(_lib.lib().lora_plan_step_region(self._h, _ptr(d_in), _ptr(d_out), int(begin), int(end), _stream(stream)),
               "lora_plan_step_region")
 
+    def step2(self, d_in, d_out, stream=None):
+        """Two applications in one launch (d_in must be an even time level; see lora_plan_step2)."""
+        check(_lib.lib().lora_plan_step2(self._h, _ptr(d_in), _ptr(d_out), _stream(stream)), "lora_plan_step2")
+
+    def step2_region(self, d_in, d_out, begin: int, end: int, stream=None):
+        check(_lib.lib().lora_plan_step2_region(self._h, _ptr(d_in), _ptr(d_out), int(begin), int(end),
+                                                _stream(stream)), "lora_plan_step2_region")
+
     def run(self, d_buf0, d_buf1, times: int, stream=None):
         """`times` sweeps ping-ponging from d_buf0; the result is in buffer [times % 2]."""
         check(_lib.lib().lora_plan_run(self._h, _ptr(d_buf0), _ptr(d_buf1), int(times), _stream(stream)),

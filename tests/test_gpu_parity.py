@@ -185,6 +185,68 @@ def test_mfma_variant_real_weights_and_scaling(L, O):
         plan.set_variant(L.VARIANT_MFMA)
 
 
+# ---------------------------------------------------------------------------------------------------------
+# temporal fusion: two applications per launch (kernels_2d_fused.hip) must equal two launches
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,dims", [("star2d1r", (64, 128)), ("star2d1r", (26, 122)), ("star2d1r", (52, 244)),
+                                        ("star2d1r", (53, 246)), ("star2d1r", (40, 130)), ("star2d1r", (1, 2)),
+                                        ("star2d1r", (300, 700)), ("box2d3r", (64, 128)), ("box2d3r", (90, 250)),
+                                        ("star2d3r", (64, 128)), ("star2d3r", (27, 124))])
+def test_fused_two_step_launches_equal_step_by_step(L, O, shape, dims):
+    a = O.reference_input(shape, dims)
+    for t in (4, 5, 6, 7):
+        got = plan_run(L, shape, a, t, options={"steps_per_launch": 2})
+        exp = O.run(shape, a, t)
+        # whole padded buffer: interior AND the halo state the step-by-step driver leaves behind
+        if np.abs(exp).max() < 2.0 ** 53:
+            assert np.array_equal(got, exp), f"{shape} {dims} t={t}"
+        else:
+            assert rel_err(got, exp) < 1e-13, f"{shape} {dims} t={t}"
+
+
+@pytest.mark.parametrize("shape,dims", [("star2d1r", (300, 700)), ("star2d1r", (1, 2)), ("star2d3r", (2100, 2600)),
+                                        ("box2d3r", (90, 250))])
+def test_fused_persistent_workgroups(L, O, shape, dims):
+    """persistent = 1: 2 workgroups per CU walk the tiles and prefetch the next window into registers."""
+    a = O.reference_input(shape, dims)
+    for t in (4, 5):
+        got = plan_run(L, shape, a, t, options={"steps_per_launch": 2, "persistent": 1})
+        assert np.array_equal(got, O.run(shape, a, t)), f"{shape} {dims} t={t}"
+
+
+def test_fused_step2_direct_call_and_regions(L, O):
+    import torch
+
+    shape, dims = "star2d1r", (200, 380)
+    a = O.reference_input(shape, dims)
+    exp = O.run(shape, a, 2)  # buffer 0 after two sweeps: interior + the input halo
+    plan = L.Plan(shape, dims)
+    assert plan.set_option("steps_per_launch", 2).kernel_name == "stencil2d_fused2_kernel"
+    src = torch.from_numpy(a).cuda()
+    dst = torch.from_numpy(a).cuda()  # same halo as the source, interior to be overwritten
+    dst[4:-4, 4:-4] = -1.0
+    plan.step2(src, dst)
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), exp)
+    dst[4:-4, 4:-4] = -1.0
+    for b, e in ((100, 200), (0, 26), (26, 100)):  # regions in any order
+        plan.step2_region(src, dst, b, e)
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), exp)
+    with pytest.raises(L.LoraError):
+        L.Plan("star3d1r", (8, 8, 8)).set_option("steps_per_launch", 2)
+
+
+def test_fused_long_run_real_weights(L, O):
+    rng = np.random.default_rng(77)
+    shape, dims = "star2d1r", (128, 512)
+    a = rng.standard_normal(O.padded_shape(shape, dims))
+    w = O.effective_weights(shape) / 100.0
+    for t in (20, 21, 22, 23):
+        got = plan_run(L, shape, a, t, weights=w, options={"steps_per_launch": 2})
+        assert rel_err(got, O.run(shape, a, t, weights=w)) < 1e-13
+
+
 @pytest.mark.parametrize("zc", [1, 2, 4, 7, 16, 40])
 def test_3d_z_chunk_does_not_change_results(L, O, zc):
     for shape in ("star3d1r", "box3d1r"):

@@ -5,7 +5,7 @@
   profiles/<tag>_pmc.json             per-kernel means of every collected counter, with the gfx950 corrections of
                                       MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB,
                                       FETCH_SIZE counts 128-B requests as 64 B for 16-B/lane streaming reads (x2)
-  profiles/pmc_traffic.json           HBM bytes per launch of the dominant kernel, keyed "<shape>:<dims>:<gpus>",
+  profiles/pmc_traffic.json           HBM bytes per launch of the dominant kernel, keyed "<shape>:<dims>:<gpus>:<kernel>",
                                       which bench.py reports as roofline.traffic
 """
 import argparse
@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--stats", default=None, help="directory of a --kernel-trace --stats run")
     ap.add_argument("--pmc", nargs="*", default=[], help="directories of --pmc runs")
     ap.add_argument("--kernel", default="stencil", help="substring of the kernels of interest")
-    ap.add_argument("--traffic-key", default=None, help='e.g. "star2d1r:16384x16384:1"')
+    ap.add_argument("--traffic-key", default=None, help='e.g. "star2d1r:16384x16384:1:stencil2d_direct_kernel"')
     args = ap.parse_args()
     prof = os.path.join(ROOT, "profiles")
     os.makedirs(prof, exist_ok=True)

@@ -52,6 +52,9 @@ def main():
     del a, b
 
     cases = [
+        ("star2d1r", (16384, 16384), {"steps_per_launch": [2], "panel_width": [16, 32, 64], "persistent": [0, 1]}),
+        ("box2d3r", (8192, 8192), {"steps_per_launch": [2], "panel_width": [32], "persistent": [0, 1]}),
+        ("star2d3r", (16384, 16384), {"steps_per_launch": [2], "panel_width": [32], "persistent": [0, 1]}),
         ("star2d1r", (16384, 16384), {"rows_per_thread": [4, 8], "panel_width": [16, 32], "variant": [1]}),
         ("star2d1r", (16384, 16384), {"panel_width": [16, 32], "variant": [2]}),
         ("box2d3r", (8192, 8192), {"rows_per_thread": [4, 8], "panel_width": [8, 16, 32, 64], "variant": [1]}),
@@ -85,7 +88,11 @@ def main():
                 else:
                     plan.set_option(k, v)
             iters = 5 if args.quick else 20
-            t = time_fn(lambda: plan.step(src, dst), iters)
+            spl = plan.get_option("steps_per_launch") if len(dims) == 2 else 1
+            if spl == 2:
+                t = time_fn(lambda: plan.step2(src, dst), iters) / 2.0  # per application
+            else:
+                t = time_fn(lambda: plan.step(src, dst), iters)
             record(kind="sweep", shape=shape, dims=dims, options=dict(zip(keys, combo)), kernel=plan.kernel_name,
                    seconds=t, gstencils=pts / t / 1e9, algo_gbs=pts * 16 / t / 1e9, frac_of_8TBs=pts * 16 / t / 8e12)
         del src, dst
