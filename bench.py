@@ -126,11 +126,17 @@ def main():
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # LORA_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
+    backend = os.environ.get("LORA_DIST_BACKEND", "nccl")
+    local_dev = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     shape = args.shape
     dims = tuple(args.size) if args.size else DEFAULT_SIZES[shape]
@@ -179,20 +185,14 @@ def main():
             plan.set_option(k, int(v))
         src0 = torch.randint(0, 100, drv.local_padded_shape, generator=gen, device=dev).to(torch.float64)
         run = lambda n: drv.run(n)  # noqa: E731
-        plan.set_option("steps_per_launch", 1) if len(dims) == 2 else None
         kernel = plan.kernel_name
-        local_points = 1
-        for d in drv.layout.local_dims:
+        local_points = drv.layout.own
+        for d in drv.layout.local_dims[1:]:
             local_points *= d
 
         def reset():
-            drv.buf[0].copy_(src0)
-            drv.buf[1].zero_()
-            drv.steps_done = 0
-            # neighbours' halos of time level 0
-            works = drv._post_exchange(drv.buf[0])
-            for wk in works:
-                wk.wait()
+            drv.load_local(src0)
+            drv.refresh_ghosts()  # neighbours' own rows of time level 0 into the ghost zones
 
     reset()
     run(W)
@@ -217,7 +217,10 @@ def main():
         points *= d
     value = points * K / elapsed / 1e9
     # one launch applies `spl` sweeps (temporal fusion); algorithmic bytes stay 2 x 8 B per point per APPLICATION
-    spl = plan.get_option("steps_per_launch") if (len(dims) == 2 and world == 1) else 1  # slabs sweep one step per launch
+    if world == 1:
+        spl = plan.get_option("steps_per_launch") if len(dims) == 2 else 1
+    else:
+        spl = 2 if drv.fused else 1
     launches = max(1, K // spl) if spl > 1 else K
     launch_s = ev_ms / 1e3 / launches  # average launch duration on the launch stream (HIP events)
     bytes_per_launch = local_points * 16.0 * (K / launches)
@@ -247,7 +250,8 @@ def main():
             "config": {
                 "workload": f"{shape} {'x'.join(map(str, dims))} fp64, {K} sweeps (lorastencil_{len(dims)}d {shape} "
                             f"{' '.join(map(str, dims))} {K})",
-                "parallelism": f"row-slabs x{world}" if world > 1 else "single GPU",
+                "parallelism": (f"row-slabs x{world}, ghost {drv.layout.ghost} rows refreshed every "
+                                f"{drv.exchange_every} launches") if world > 1 else "single GPU",
                 "kernel": kernel,
                 "variant": {1: "direct", 2: "mfma"}.get(plan.get_option("variant"), "?"),
                 "normalised_taps": bool(normalised),

@@ -2,22 +2,32 @@
 
 The reference is single-GPU (no NCCL/MPI call sites); this is the multi-GPU form the north star
 asks for.  The outermost interior dimension (rows in 2D, planes in 3D, points in 1D) is cut into contiguous
-slabs, one per rank of a ``torch.distributed`` process group (backend "nccl" = RCCL on ROCm).  Each rank keeps
-its slab in the SAME padded layout the single-GPU operator uses, so the slab kernels are the single-GPU kernels:
+slabs, one per rank of a ``torch.distributed`` process group (backend "nccl" = RCCL on ROCm).
 
-* the local halo next to a neighbour holds that neighbour's boundary interior rows of the same time level and is
-  refreshed by one send/recv pair per neighbour per step (`radius` rows/planes: 3 in 2D, 1 in 3D, 4 in 1D);
-* the local halo at a global edge keeps the reference's semantics untouched: never written, i.e. the caller's
-  input halo in buffer 0 and zeros in buffer 1 (SURVEY B2);
-* per step the two boundary strips are computed first, their exchange is posted (it runs on the process group's
-  own stream), then the interior is computed while the messages are in flight; the next step waits for both.
+Layout of a rank's local array (same padded layout as the single-GPU operator, so the slab kernels ARE the
+single-GPU kernels)::
 
-Per-point arithmetic is identical to the single-GPU sweep (same kernel, same tap order), so an N-rank result is
+      [ pad ][ G ghost rows of the upper neighbour ][ ml own rows ][ G ghost rows of the lower one ][ pad ]
+
+* Ghost rows are ordinary interior rows of the local problem.  A launch that advances the grid by ``need`` rows of
+  reach (radius x applications per launch: 3 or 6 in 2D, 1 in 3D, 4 in 1D) is run on the own rows plus the ghost rows
+  that are still needed later, after which ``need`` fewer ghost rows are valid.  Ghost zones are G = need x E deep and
+  are refreshed from the neighbours' own rows every E launches (communication-avoiding: E x fewer, E x larger
+  messages -- at 8 GPUs a 2048 x 16384 slab sweeps in ~65 us, so per-launch host work and P2P latency, not
+  bandwidth, are what has to be amortised).  Redundant work: E(E-1)/2 x need ghost rows per side per period.
+* On the launch that exhausts the ghost zone the two own boundary strips are swept first, their exchange is posted
+  (it runs on the process group's own stream) and the interior is swept while the messages are in flight.
+* A rank at a global edge has no ghost rows there: its pad rows are the global halo and keep the reference's
+  semantics untouched (never written: the caller's input halo at even time levels, zeros at odd ones).
+* 2D shapes with the 25- or 13-tap sets use the fused two-application launches (``Plan.step2_region``) exactly like
+  the single-GPU driver: both physical buffers then carry the level-0 halo ring, odd tails are single sweeps.
+
+Per-point arithmetic is identical to the single-GPU sweep (same kernels, same tap order), so an N-rank result is
 bit-identical to the 1-rank result.
 
-The sweep itself is delegated to a *stepper* (``step_region(src, dst, begin, end)``).  The product stepper is
+The sweep itself is delegated to a *stepper* (``step_region`` / ``step2_region``).  The product stepper is
 ``HipStepper`` (the HIP engine through ``ops.Plan``); there is no CPU stepper in this package -- the gloo tests
-inject one built on the oracle to exercise the decomposition and exchange logic on CPU.
+inject one to exercise the decomposition, ghost-zone bookkeeping and exchange logic on CPU.
 """
 from __future__ import annotations
 
@@ -33,7 +43,7 @@ from . import ops
 
 @dataclass(frozen=True)
 class SlabLayout:
-    """Which part of the global grid a rank owns (outermost interior dimension only)."""
+    """Which part of the global grid a rank owns (outermost interior dimension only) and its ghost depth."""
 
     shape: int
     global_dims: tuple
@@ -41,10 +51,23 @@ class SlabLayout:
     rank: int
     begin: int  # first global interior index of the slab
     end: int  # one past the last
+    ghost: int = 0  # ghost rows per neighbour side
+
+    @property
+    def own(self) -> int:
+        return self.end - self.begin
+
+    @property
+    def ghost_top(self) -> int:
+        return self.ghost if self.rank > 0 else 0
+
+    @property
+    def ghost_bottom(self) -> int:
+        return self.ghost if self.rank < self.world_size - 1 else 0
 
     @property
     def local_dims(self) -> tuple:
-        return (self.end - self.begin,) + tuple(self.global_dims[1:])
+        return (self.ghost_top + self.own + self.ghost_bottom,) + tuple(self.global_dims[1:])
 
     @property
     def halo0(self) -> int:
@@ -52,13 +75,14 @@ class SlabLayout:
 
     @property
     def radius0(self) -> int:
-        """Stencil reach along the split dimension = rows/planes exchanged per neighbour per step."""
+        """Stencil reach along the split dimension per application."""
         return {1: 4, 2: 3, 3: 1}[len(self.global_dims)]
 
 
-def slab_layout(shape, global_dims: Sequence[int], world_size: int, rank: int, multiple: int | None = None) -> SlabLayout:
-    """Balanced contiguous split; every slab boundary is a multiple of ``multiple`` (default: 32 rows in 2D so
-    that slabs are whole tile rows, 2 points in 1D, 1 plane in 3D)."""
+def slab_layout(shape, global_dims: Sequence[int], world_size: int, rank: int, multiple: int | None = None,
+                ghost: int = 0) -> SlabLayout:
+    """Balanced contiguous split; every slab boundary is a multiple of ``multiple`` (default: 32 rows in 2D,
+    2 points in 1D, 1 plane in 3D)."""
     sid = ops.shape_id(shape)
     nd = len(global_dims)
     if multiple is None:
@@ -71,22 +95,29 @@ def slab_layout(shape, global_dims: Sequence[int], world_size: int, rank: int, m
     start_u = rank * base + min(rank, extra)
     end_u = start_u + base + (1 if rank < extra else 0)
     begin, end = start_u * multiple, min(end_u * multiple, n0)
-    lay = SlabLayout(sid, tuple(int(d) for d in global_dims), world_size, rank, begin, end)
-    if end - begin < lay.radius0:
-        raise ValueError("slab thinner than the stencil radius")
+    lay = SlabLayout(sid, tuple(int(d) for d in global_dims), world_size, rank, begin, end, ghost if world_size > 1 else 0)
+    if world_size > 1 and end - begin < max(lay.radius0, ghost):
+        raise ValueError("slab thinner than its ghost zone")
     return lay
 
 
 class HipStepper:
-    """Product stepper: the HIP engine on the local slab."""
+    """Product stepper: the HIP engine on the local array (own rows + ghost rows)."""
 
     def __init__(self, layout: SlabLayout, params=None, weights=None):
         self.plan = ops.Plan(layout.shape, layout.local_dims, params)
         if weights is not None:
             self.plan.set_weights(weights)
 
+    @property
+    def wants_fused(self) -> bool:
+        return self.plan.get_option("steps_per_launch") == 2
+
     def step_region(self, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
         self.plan.step_region(src, dst, begin, end)
+
+    def step2_region(self, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
+        self.plan.step2_region(src, dst, begin, end)
 
 
 class SlabDriver:
@@ -94,56 +125,90 @@ class SlabDriver:
 
     def __init__(self, shape, global_dims: Sequence[int], group=None, device=None, params=None, weights=None,
                  stepper_factory: Callable[[SlabLayout], object] | None = None, overlap: bool = True,
-                 boundary_rows: int | None = None):
+                 exchange_every: int | None = None, fused: bool | None = None, boundary_rows: int | None = None):
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self.layout = slab_layout(shape, global_dims, self.world_size, self.rank)
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
-        if stepper_factory is None:
-            self.stepper = HipStepper(self.layout, params=params, weights=weights)
-        else:
-            self.stepper = stepper_factory(self.layout)
+        sid = ops.shape_id(shape)
+        nd = len(global_dims)
+        self.ndim = nd
+        # a first, ghost-free layout tells how thick the slabs are; the ghost depth is then fitted to them
+        probe = slab_layout(sid, global_dims, self.world_size, self.rank)
+        radius = probe.radius0
+        if fused is None:
+            fused = (nd == 2)  # refined below by what the stepper supports
+        self._make_stepper = stepper_factory or (lambda lay: HipStepper(lay, params=params, weights=weights))
+        # thinnest slab of the decomposition bounds the ghost depth (neighbours supply ghost rows from own rows)
+        thinnest = min(slab_layout(sid, global_dims, self.world_size, r).own for r in range(self.world_size))
+        if exchange_every is None:
+            exchange_every = 4
+        layout = None
+        for try_fused in ([True, False] if fused else [False]):
+            need = radius * (2 if try_fused else 1)
+            e = max(1, min(exchange_every, thinnest // need if self.world_size > 1 else exchange_every))
+            if self.world_size > 1 and thinnest < need:
+                continue
+            layout = slab_layout(sid, global_dims, self.world_size, self.rank, ghost=need * e)
+            stepper = self._make_stepper(layout)
+            if try_fused and not (hasattr(stepper, "step2_region") and getattr(stepper, "wants_fused", True)):
+                continue  # e.g. 49-tap box: the engine prefers single sweeps
+            self.fused, self.need, self.exchange_every = try_fused, need, e
+            self.stepper = stepper
+            break
+        if layout is None or not hasattr(self, "stepper"):
+            raise ValueError("slabs are thinner than the stencil radius")
+        self.layout = layout
+        self.radius = radius
         self.overlap = overlap
-        lay = self.layout
-        self.local_padded_shape = ops.padded_shape(lay.shape, lay.local_dims)
+        self.local_padded_shape = ops.padded_shape(sid, layout.local_dims)
         self.buf = [torch.zeros(self.local_padded_shape, dtype=torch.float64, device=self.device) for _ in range(2)]
-        n_local = lay.end - lay.begin
-        # rows of each boundary strip: at least the radius, by default one tile row of the 2D kernel
         if boundary_rows is None:
-            boundary_rows = {1: 2048, 2: 32, 3: 1}[len(lay.global_dims)]
-        self.strip = max(lay.radius0, min(boundary_rows, n_local // 2)) if self.world_size > 1 else 0
-        if self.strip and len(lay.global_dims) == 1:
+            boundary_rows = {1: 4096, 2: 32, 3: 1}[nd]
+        self.strip = max(layout.ghost, min(boundary_rows, layout.own // 2))
+        if nd == 1:
             self.strip += self.strip & 1  # 1D regions start on even points
         self.up = self.rank - 1 if self.rank > 0 else None  # neighbour owning smaller indices
         self.down = self.rank + 1 if self.rank < self.world_size - 1 else None
         self.steps_done = 0
+        self.cur = 0  # physical buffer holding the current time level
+        self.valid = layout.ghost  # ghost rows per side that hold the current time level
+        self.ring = ["input", "zero"]  # what the halo ring of each physical buffer holds (fused 2D bookkeeping)
 
     # ---- data movement between the global padded array and the slabs ---------------------------------
     def load_global(self, global_padded) -> None:
-        """buffer 0 <- this rank's rows of the global padded input (its halos included), buffer 1 <- 0."""
+        """buffer 0 <- this rank's rows of the global padded input (ghost rows and pads included), buffer 1 <- 0."""
         lay = self.layout
         h0 = lay.halo0
-        sl = slice(lay.begin, lay.end + 2 * h0)  # padded rows begin .. end+2*halo of the global array
-        part = global_padded[sl]
+        lo = lay.begin - lay.ghost_top
+        hi = lay.end + lay.ghost_bottom + 2 * h0
+        part = global_padded[lo:hi]
         if isinstance(part, np.ndarray):
             part = torch.from_numpy(np.ascontiguousarray(part))
         self.buf[0].copy_(part.to(self.device))
         self.buf[1].zero_()
-        self.steps_done = 0
+        self.steps_done, self.cur, self.valid = 0, 0, lay.ghost
+        self.ring = ["input", "zero"]
+
+    def load_local(self, local_padded: torch.Tensor) -> None:
+        """Same from an already-local array (own rows + ghost rows + pads), e.g. generated on the device."""
+        self.buf[0].copy_(local_padded)
+        self.buf[1].zero_()
+        self.steps_done, self.cur, self.valid = 0, 0, self.layout.ghost
+        self.ring = ["input", "zero"]
 
     def result(self) -> torch.Tensor:
-        """The local padded buffer holding the current time level (buffer [steps % 2])."""
-        return self.buf[self.steps_done % 2]
+        """The local padded buffer holding the current time level."""
+        return self.buf[self.cur]
 
     def gather_global(self, dst_rank: int = 0):
-        """Assemble the global padded result on ``dst_rank`` (interiors from every slab, global-edge halos from
-        the edge ranks; left/right halos travel with the rows).  Returns a CPU tensor there, None elsewhere."""
+        """Assemble the global padded result on ``dst_rank`` (own rows of every slab, global-edge halos from the
+        edge ranks; left/right halos travel with the rows).  Returns a CPU tensor there, None elsewhere."""
         lay = self.layout
         h0 = lay.halo0
         cur = self.result()
-        lo = 0 if self.up is None else h0
-        hi = cur.shape[0] if self.down is None else cur.shape[0] - h0
+        lo = 0 if self.up is None else h0 + lay.ghost_top
+        hi = cur.shape[0] if self.down is None else h0 + lay.ghost_top + lay.own
         piece = cur[lo:hi].cpu()
         if self.world_size == 1:
             return piece
@@ -153,44 +218,101 @@ class SlabDriver:
             return None
         return torch.cat(pieces, dim=0)
 
-    # ---- one time step ---------------------------------------------------------------------------------
-    def _post_exchange(self, dst: torch.Tensor):
+    # ---- halo-ring bookkeeping of the fused 2D path -----------------------------------------------------
+    def _set_ring(self, b: int, what: str, src: int) -> None:
+        """Global-edge halo ring of physical buffer b: 'input' (copy of buffer src's ring) or 'zero'."""
+        if self.ndim != 2 or self.ring[b] == what:
+            return
+        t = self.buf[b]
+        if what == "zero":
+            t[:4].zero_()
+            t[-4:].zero_()
+            t[:, :4].zero_()
+            t[:, -4:].zero_()
+        else:
+            s = self.buf[src]
+            t[:4].copy_(s[:4])
+            t[-4:].copy_(s[-4:])
+            t[:, :4].copy_(s[:, :4])
+            t[:, -4:].copy_(s[:, -4:])
+        self.ring[b] = what
+
+    # ---- ghost exchange ---------------------------------------------------------------------------------
+    def _post_exchange(self, t: torch.Tensor):
+        """Own boundary rows of ``t`` -> the neighbours' ghost zones (G rows each way)."""
         lay = self.layout
-        h0, r = lay.halo0, lay.radius0
-        n_local = lay.end - lay.begin
+        g = lay.ghost
+        first = lay.halo0 + lay.ghost_top  # padded index of the first own row
+        last = first + lay.own
         opsl = []
         if self.up is not None:
-            opsl.append(dist.P2POp(dist.isend, dst[h0:h0 + r], self.up, group=self.group))
-            opsl.append(dist.P2POp(dist.irecv, dst[h0 - r:h0], self.up, group=self.group))
+            opsl.append(dist.P2POp(dist.isend, t[first:first + g], self.up, group=self.group))
+            opsl.append(dist.P2POp(dist.irecv, t[first - g:first], self.up, group=self.group))
         if self.down is not None:
-            opsl.append(dist.P2POp(dist.isend, dst[h0 + n_local - r:h0 + n_local], self.down, group=self.group))
-            opsl.append(dist.P2POp(dist.irecv, dst[h0 + n_local:h0 + n_local + r], self.down, group=self.group))
+            opsl.append(dist.P2POp(dist.isend, t[last - g:last], self.down, group=self.group))
+            opsl.append(dist.P2POp(dist.irecv, t[last:last + g], self.down, group=self.group))
         return dist.batch_isend_irecv(opsl) if opsl else []
 
-    def step(self) -> None:
-        src = self.buf[self.steps_done % 2]
-        dst = self.buf[(self.steps_done + 1) % 2]
-        n_local = self.layout.end - self.layout.begin
-        st = self.stepper
+    def refresh_ghosts(self) -> None:
+        """Blocking refresh of the ghost zones of the current buffer (used after loading device-generated data)."""
+        if self.world_size > 1:
+            for w in self._post_exchange(self.buf[self.cur]):
+                w.wait()
+        self.valid = self.layout.ghost
+
+    # ---- one launch (1 or 2 applications) ---------------------------------------------------------------
+    def _launch(self, fused: bool) -> None:
+        lay = self.layout
+        need = self.radius * (2 if fused else 1)
+        src_i, dst_i = self.cur, 1 - self.cur
+        src, dst = self.buf[src_i], self.buf[dst_i]
+        sweep = self.stepper.step2_region if fused else self.stepper.step_region
+        if self.ndim == 2 and (self.fused or fused):
+            # fused launches need the level-0 ring in both buffers; a single sweep from an even level writes the
+            # odd level, whose ring is 0 (SURVEY B2); from an odd level it writes an even one (ring = input)
+            even = self.steps_done % 2 == 0
+            self._set_ring(dst_i, "input" if (fused or not even) else "zero", src_i)
+        gt, own = lay.ghost_top, lay.own
         if self.world_size == 1:
-            st.step_region(src, dst, 0, n_local)
-        elif self.overlap and n_local > 2 * self.strip:
-            s = self.strip
-            # boundary strips first, so that their exchange overlaps the interior sweep
-            if self.up is not None:
-                st.step_region(src, dst, 0, s)
-            if self.down is not None:
-                st.step_region(src, dst, n_local - s, n_local)
-            works = self._post_exchange(dst)
-            st.step_region(src, dst, s if self.up is not None else 0, n_local - s if self.down is not None else n_local)
-            for w in works:
-                w.wait()
+            sweep(src, dst, 0, own)
         else:
-            st.step_region(src, dst, 0, n_local)
-            for w in self._post_exchange(dst):
-                w.wait()
-        self.steps_done += 1
+            assert self.valid >= need, "ghost zone exhausted"
+            left = self.valid - need  # ghost rows still valid after this launch
+            exchange = left < self.need  # not enough for another launch of this driver's kind: refresh now
+            if exchange:
+                s = self.strip
+                if self.overlap and own > 2 * s:
+                    if self.up is not None:
+                        sweep(src, dst, gt, gt + s)
+                    if self.down is not None:
+                        sweep(src, dst, gt + own - s, gt + own)
+                    works = self._post_exchange(dst)
+                    sweep(src, dst, gt + (s if self.up is not None else 0), gt + own - (s if self.down is not None else 0))
+                else:
+                    sweep(src, dst, gt, gt + own)
+                    works = self._post_exchange(dst)
+                for w in works:
+                    w.wait()
+                self.valid = lay.ghost
+            else:
+                lo = gt - (left if self.up is not None else 0)
+                hi = gt + own + (left if self.down is not None else 0)
+                sweep(src, dst, lo, hi)
+                self.valid = left
+        self.cur = dst_i
+        self.steps_done += 2 if fused else 1
+
+    def step(self) -> None:
+        """One kernel application."""
+        self._launch(False)
 
     def run(self, times: int) -> None:
-        for _ in range(times):
-            self.step()
+        """`times` kernel applications (fused pairs where the shape allows, starting at even time levels)."""
+        t = 0
+        while t < times:
+            if self.fused and self.steps_done % 2 == 0 and times - t >= 2:
+                self._launch(True)
+                t += 2
+            else:
+                self._launch(False)
+                t += 1

@@ -366,12 +366,14 @@ def test_slab_driver_single_rank_on_gpu(L, O):
     """world_size 1: SlabDriver + HipStepper reproduce the operator (the N > 1 exchange is covered on CPU/gloo)."""
     from lorastencil_amd import slab
 
-    shape, dims, t = "star2d1r", (128, 256), 3
-    a = O.reference_input(shape, dims)
-    drv = slab.SlabDriver(shape, dims, device="cuda:0")
-    drv.load_global(a)
-    drv.run(t)
-    assert np.array_equal(drv.gather_global().numpy(), O.run(shape, a, t))
+    for shape, dims, t in (("star2d1r", (128, 256), 7), ("box2d3r", (64, 128), 3), ("star3d1r", (9, 16, 64), 4)):
+        a = O.reference_input(shape, dims)
+        drv = slab.SlabDriver(shape, dims, device="cuda:0")
+        assert drv.fused == (shape == "star2d1r")
+        drv.load_global(a)
+        drv.run(3)
+        drv.run(t - 3)
+        assert np.array_equal(drv.gather_global().numpy(), O.run(shape, a, t)), shape
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -20,16 +20,31 @@ if ROOT not in sys.path:
 class OracleStepper:
     """CPU stand-in for HipStepper (tests only)."""
 
-    def __init__(self, layout, weights):
+    def __init__(self, layout, weights, wants_fused=True):
         from lorastencil_amd import ops
 
         self.shape = layout.shape
         self.w = weights
         self.h = ops.halo(layout.shape)
+        self.wants_fused = wants_fused and len(self.h) == 2
+        self.calls = {"step": 0, "step2": 0}
+
+    def step2_region(self, src, dst, begin, end):
+        """Two applications with the intermediate level's out-of-interior cells = 0 (lora_plan_step2_region)."""
+        from oracle import oracle as O
+
+        self.calls["step2"] += 1
+        if end <= begin:
+            return
+        mid = O.step(self.shape, np.ascontiguousarray(src.numpy()), self.w)  # zeros outside the local interior
+        out = O.step(self.shape, mid, self.w)
+        h0, h1 = self.h
+        dst.numpy()[h0 + begin:h0 + end, h1:-h1] = out[h0 + begin:h0 + end, h1:-h1]
 
     def step_region(self, src, dst, begin, end):
         from oracle import oracle as O
 
+        self.calls["step"] += 1
         if end <= begin:
             return
         h0 = self.h[0]
@@ -40,7 +55,7 @@ class OracleStepper:
         d[inner] = out[inner]
 
 
-def _worker(rank, world, port, shape, dims, times, overlap, q):
+def _worker(rank, world, port, shape, dims, times, overlap, q, fused=None, exchange_every=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -50,13 +65,16 @@ def _worker(rank, world, port, shape, dims, times, overlap, q):
 
         a = O.reference_input(shape, dims)
         w = O.effective_weights(shape)
-        drv = slab.SlabDriver(shape, dims, device="cpu", overlap=overlap, boundary_rows=4,
-                              stepper_factory=lambda lay: OracleStepper(lay, w))
+        drv = slab.SlabDriver(shape, dims, device="cpu", overlap=overlap, boundary_rows=4, fused=fused,
+                              exchange_every=exchange_every,
+                              stepper_factory=lambda lay: OracleStepper(lay, w, wants_fused=fused is not False))
         drv.load_global(a)
-        drv.run(times)
+        # split the run in two calls: the driver must be resumable at any time level
+        drv.run(times // 2)
+        drv.run(times - times // 2)
         full = drv.gather_global(0)
         if rank == 0:
-            q.put(full.numpy())
+            q.put((full.numpy(), drv.fused, drv.exchange_every, drv.layout.ghost, dict(drv.stepper.calls)))
     finally:
         dist.destroy_process_group()
 
@@ -67,18 +85,19 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_slabs(world, shape, dims, times, overlap=True):
+def run_slabs(world, shape, dims, times, overlap=True, fused=None, exchange_every=None, info=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, dims, times, overlap, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, dims, times, overlap, q, fused, exchange_every))
+             for r in range(world)]
     for p in procs:
         p.start()
-    out = q.get(timeout=120)
+    out = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    return out
+    return out if info else out[0]
 
 
 @pytest.mark.parametrize("world,shape,dims,times", [
@@ -99,6 +118,31 @@ def test_slabs_equal_single_rank(engine_built, world, shape, dims, times):
         expect[-1] = got[-1]
     assert got.shape == expect.shape
     assert np.array_equal(got, expect)
+
+
+@pytest.mark.parametrize("world,shape,dims,times,every", [
+    (2, "star2d1r", (128, 64), 7, 1),     # fused pairs + odd tail, ghost zone refreshed after every launch
+    (2, "star2d1r", (128, 64), 10, 4),    # communication-avoiding: 24-row ghost zones, exchange every 4 launches
+    (3, "star2d3r", (192, 32), 9, 2),
+    (2, "star3d1r", (16, 8, 16), 7, 3),   # single sweeps, 3-plane ghost zones exchanged every 3 steps
+    (3, "box2d3r", (192, 32), 5, 2),      # 49-tap box: the stepper declines fusion
+    (2, "1d2r", (8192,), 5, 2),
+])
+def test_ghost_zone_schedules_equal_single_rank(engine_built, world, shape, dims, times, every):
+    from oracle import oracle as O
+
+    a = O.reference_input(shape, dims)
+    expect = O.run(shape, a, times)
+    fused = None if shape != "box2d3r" else False
+    got, was_fused, e, ghost, calls = run_slabs(world, shape, dims, times, fused=fused, exchange_every=every, info=True)
+    if expect.ndim == 1:
+        expect[-1] = got[-1]
+    assert np.array_equal(got, expect)
+    radius = {1: 4, 2: 3, 3: 1}[len(dims)]
+    assert e == every and ghost == radius * (2 if was_fused else 1) * every
+    assert was_fused == (len(dims) == 2 and shape != "box2d3r")
+    if was_fused:
+        assert calls["step2"] > 0
 
 
 def test_slabs_without_overlap_path(engine_built):
