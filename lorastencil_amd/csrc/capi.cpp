@@ -136,14 +136,15 @@ void plan_refresh(Plan &p) {
         p.tapset = star ? TAPS2D_STAR : (diamond ? TAPS2D_DIAMOND : TAPS2D_BOX);
         derive_lowrank(p);
         if (p.variant == LORA_VARIANT_MFMA && !p.lowrank_valid) p.variant = LORA_VARIANT_DIRECT;
-        // temporal fusion pays where the sweep is HBM-bound (25- and 13-tap sets: 554 / 625 vs 352 / 345 GStencils/s
-        // on 16384^2, profiles/); the 49-tap box is FMA-bound either way (337 vs 350) and stays single-sweep
+        // temporal fusion (two applications per launch) wins for every tap set once the tile height is tuned
+        // (16384^2 / 8192^2, profiles/r01_sweep_fused_rows.jsonl: 25 taps 602 vs 352 GStencils/s, 13 taps 649 vs
+        // 345, 49 taps 400 vs 350); the light 13-tap star prefers the small tile (more workgroups per CU), the
+        // FMA-heavier sets the tall one (less recomputed halo)
         if (p.variant == LORA_VARIANT_MFMA)
             p.steps_per_launch = 1;
-        else if (p.steps_per_launch_req == 0)
-            p.steps_per_launch = (p.tapset == TAPS2D_BOX) ? 1 : 2;
         else
-            p.steps_per_launch = p.steps_per_launch_req;
+            p.steps_per_launch = p.steps_per_launch_req == 0 ? 2 : p.steps_per_launch_req;
+        p.fused_rows = p.fused_rows_req ? p.fused_rows_req : (p.tapset == TAPS2D_STAR ? 6 : 10);
         p.kernel_name = (p.variant == LORA_VARIANT_MFMA)
                             ? kernel_name_2d_mfma(p)
                             : (p.steps_per_launch == 2 ? kernel_name_2d_fused2(p) : kernel_name_2d_direct(p));
@@ -317,6 +318,9 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         p.nt_store = value ? 1 : 0;
     } else if (!std::strcmp(key, "persistent")) {
         p.persistent = value ? 1 : 0;
+    } else if (!std::strcmp(key, "fused_rows")) {
+        if (value != 0 && value != 6 && value != 8 && value != 10) return LORA_EINVAL;
+        p.fused_rows_req = value;
     } else if (!std::strcmp(key, "steps_per_launch")) {
         if (value < 0 || value > 2) return LORA_EINVAL;
         if (value == 2 && (p.ndim != 2 || p.variant != LORA_VARIANT_DIRECT)) return LORA_EUNSUPPORTED;
@@ -342,6 +346,8 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.nt_store;
     else if (!std::strcmp(key, "persistent"))
         *value = p.persistent;
+    else if (!std::strcmp(key, "fused_rows"))
+        *value = p.fused_rows;
     else if (!std::strcmp(key, "steps_per_launch"))
         *value = p.steps_per_launch;
     else if (!std::strcmp(key, "tapset"))

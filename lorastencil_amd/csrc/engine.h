@@ -53,6 +53,8 @@ struct Plan {
     int rows_per_thread = 8;  // 2D direct: output rows per lane (tile height = 4x this)
     int panel_width = 32;     // 2D: tile columns per L2 panel of the block->tile map
     int nt_store = 0;         // 2D: non-temporal output stores
+    int fused_rows_req = 0;   // 0 = auto, else 6 / 8 / 10
+    int fused_rows = 8;       // 2D fused: intermediate rows per wave (tile = 4x this - 6 output rows), resolved
     int persistent = 0;       // 2D fused: persistent workgroups with register prefetch of the next tile
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
     int steps_per_launch_req = 0;  // 0 = auto (fused for the diamond / star tap sets), 1, 2

@@ -21,7 +21,8 @@
 // Shifting each level's lane->column map by 3 makes every 7-tap window of a lane's column pair an ALIGNED 8-wide
 // LDS window: 4 x ds_read_b128 per row and level (the single-sweep kernel needs 5).
 // Cost of fusing: the intermediate tile is 1.29 x the output tile (recomputed halo), 30 instead of 25 FMAs per
-// point and application; LDS 74 KiB per workgroup -> 2 workgroups per CU.
+// point and application.  The intermediate tile overwrites the input window in LDS once it has been consumed
+// (41 KiB per workgroup -> 3 workgroups per CU).
 #include <hip/hip_runtime.h>
 
 #include "device_common.h"
@@ -43,11 +44,11 @@ struct ArgsFused {
     int tiles_x, tiles_y, panel_w;
 };
 
-// PERSIST: the grid is 2 workgroups per CU; each walks its XCD's run of tiles and fetches the next tile's input
+// PERSIST: the grid is 3 workgroups per CU; each walks its XCD's run of tiles and fetches the next tile's input
 // window into registers while the current tile is being computed, so the HBM latency of a tile is hidden behind
 // the two applications of the previous one instead of behind the other resident workgroup only.
 template <int TAPSET, int R1, bool PERSIST>
-__global__ __launch_bounds__(256, 2) void stencil2d_fused2_kernel(const ArgsFused a, const Taps49 W) {
+__global__ __launch_bounds__(256, 3) void stencil2d_fused2_kernel(const ArgsFused a, const Taps49 W) {
     constexpr int IH = 4 * R1;            // intermediate rows
     constexpr int TH = IH - 6;            // output rows
     constexpr int AH = IH + 6;            // input rows
@@ -55,8 +56,11 @@ __global__ __launch_bounds__(256, 2) void stencil2d_fused2_kernel(const ArgsFuse
     constexpr int BH = 3 * R2 + R2 + 6;   // rows of B the last wave may touch (rows >= IH are never written)
     constexpr int NCHUNK = AH * kInChunks;
     constexpr int NIT = (NCHUNK + 255) / 256;
+    // One LDS array: the input window A, then -- once every wave has finished application 1 -- the intermediate
+    // tile B written over it from registers.  41 KB per workgroup -> 3 workgroups per CU instead of 2.
+    static_assert((BH > IH ? BH : IH) * kMidW <= AH * kInW, "B must fit in A's space");
     __shared__ __attribute__((aligned(16))) double A[AH * kInW];
-    __shared__ __attribute__((aligned(16))) double B[(BH > IH ? BH : IH) * kMidW];
+    double *const B = A;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
@@ -159,19 +163,20 @@ __global__ __launch_bounds__(256, 2) void stencil2d_fused2_kernel(const ArgsFuse
             for (int r = 0; r < R1; ++r) {
                 if (j - r >= 0 && j - r < 7) asm volatile("" : "+v"(acc0[r]), "+v"(acc1[r]));
             }
-            if (j >= 6) {
-                const int r = j - 6;
-                const int im = i0 - 3 + wv * R1 + r;  // interior row of this intermediate row
-                const bool row_in = im >= 0 && im < a.m;
-                d2 v;
-                // cells outside the interior are halo cells of "buffer 1": never written, always 0
-                v.x = (row_in && c0_in) ? acc0[r] : 0.0;
-                v.y = (row_in && c1_in) ? acc1[r] : 0.0;
-                *reinterpret_cast<d2 *>(B + (wv * R1 + r) * kMidW + 2 * lane) = v;
-            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
             __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();  // every wave has consumed its part of A: its space now takes the intermediate tile
+#pragma unroll
+        for (int r = 0; r < R1; ++r) {
+            const int im = i0 - 3 + wv * R1 + r;  // interior row of this intermediate row
+            const bool row_in = im >= 0 && im < a.m;
+            d2 v;
+            // cells outside the interior are halo cells of "buffer 1": never written, always 0
+            v.x = (row_in && c0_in) ? acc0[r] : 0.0;
+            v.y = (row_in && c1_in) ? acc1[r] : 0.0;
+            *reinterpret_cast<d2 *>(B + (wv * R1 + r) * kMidW + 2 * lane) = v;
         }
     }
     __syncthreads();
@@ -236,7 +241,8 @@ __global__ __launch_bounds__(256, 2) void stencil2d_fused2_kernel(const ArgsFuse
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    }  // tile loop: A is rewritten only after the barrier that followed application 1, B only after the next one
+    if (PERSIST) __syncthreads();  // B lives in A's space: the next window may land only after application 2
+    }  // tile loop
 }
 
 // Halo ring of a padded (m+8) x (n+8) array: dst <- src (src != nullptr) or dst <- 0.
@@ -260,9 +266,8 @@ __global__ void halo_ring_kernel(double *__restrict__ dst, const double *__restr
     }
 }
 
-template <int TAPSET>
+template <int TAPSET, int R1>
 hipError_t launch_fused2_t(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
-    constexpr int R1 = 8;
     constexpr int TH = 4 * R1 - 6;
     ArgsFused a;
     a.in = in;
@@ -281,13 +286,13 @@ hipError_t launch_fused2_t(const Plan &p, const double *in, double *out, int beg
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
     if (p.persistent) {
-        // 2 resident workgroups per CU (LDS-limited), a multiple of 8 so that every XCD gets the same count
+        // 3 resident workgroups per CU (LDS-limited), a multiple of 8 so that every XCD gets the same count
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) {
             int v = 0;
             if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
         }
-        long grid = 2L * cus;
+        long grid = 3L * cus;
         if (grid > nblocks) grid = nblocks;
         hipLaunchKernelGGL((stencil2d_fused2_kernel<TAPSET, R1, true>), dim3((unsigned) grid), dim3(256), 0, s, a, w);
     } else {
@@ -299,14 +304,19 @@ hipError_t launch_fused2_t(const Plan &p, const double *in, double *out, int beg
 }  // namespace
 
 hipError_t launch_2d_fused2(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
-    switch (p.tapset) {
-        case TAPS2D_DIAMOND:
-            return launch_fused2_t<TAPS2D_DIAMOND>(p, in, out, begin, end, s);
-        case TAPS2D_STAR:
-            return launch_fused2_t<TAPS2D_STAR>(p, in, out, begin, end, s);
-        default:
-            return launch_fused2_t<TAPS2D_BOX>(p, in, out, begin, end, s);
+#define LORA_FUSED_DISPATCH(R1)                                                        \
+    switch (p.tapset) {                                                                 \
+        case TAPS2D_DIAMOND:                                                            \
+            return launch_fused2_t<TAPS2D_DIAMOND, R1>(p, in, out, begin, end, s);     \
+        case TAPS2D_STAR:                                                               \
+            return launch_fused2_t<TAPS2D_STAR, R1>(p, in, out, begin, end, s);        \
+        default:                                                                        \
+            return launch_fused2_t<TAPS2D_BOX, R1>(p, in, out, begin, end, s);         \
     }
+    if (p.fused_rows == 6) { LORA_FUSED_DISPATCH(6) }
+    if (p.fused_rows == 10) { LORA_FUSED_DISPATCH(10) }
+    LORA_FUSED_DISPATCH(8)
+#undef LORA_FUSED_DISPATCH
 }
 
 hipError_t launch_halo_ring_2d(const Plan &p, double *dst, const double *src, hipStream_t s) {

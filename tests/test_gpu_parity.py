@@ -214,6 +214,14 @@ def test_fused_persistent_workgroups(L, O, shape, dims):
         assert np.array_equal(got, O.run(shape, a, t)), f"{shape} {dims} t={t}"
 
 
+@pytest.mark.parametrize("rows", [6, 8, 10])
+def test_fused_tile_heights(L, O, rows):
+    for shape, dims in (("star2d1r", (150, 380)), ("box2d3r", (70, 130))):
+        a = O.reference_input(shape, dims)
+        got = plan_run(L, shape, a, 4, options={"steps_per_launch": 2, "fused_rows": rows})
+        assert np.array_equal(got, O.run(shape, a, 4)), (shape, rows)
+
+
 def test_fused_step2_direct_call_and_regions(L, O):
     import torch
 
@@ -369,7 +377,7 @@ def test_slab_driver_single_rank_on_gpu(L, O):
     for shape, dims, t in (("star2d1r", (128, 256), 7), ("box2d3r", (64, 128), 3), ("star3d1r", (9, 16, 64), 4)):
         a = O.reference_input(shape, dims)
         drv = slab.SlabDriver(shape, dims, device="cuda:0")
-        assert drv.fused == (shape == "star2d1r")
+        assert drv.fused == (len(dims) == 2)  # every 2D tap set uses the fused two-application launches
         drv.load_global(a)
         drv.run(3)
         drv.run(t - 3)
