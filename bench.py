@@ -44,6 +44,7 @@ def parse_args():
     ap.add_argument("--size", type=int, nargs="+", default=None, help="interior sizes (default: the BASELINE config)")
     ap.add_argument("--option", action="append", default=[], help="plan option key=value (e.g. rows_per_thread=4)")
     ap.add_argument("--variant", choices=["auto", "direct", "mfma"], default="auto")
+    ap.add_argument("--dtype", choices=["f64", "bf16"], default="f64", help="bf16: 3D shapes only (BASELINE config 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -139,14 +140,19 @@ def main():
             dist.init_process_group(backend)
 
     shape = args.shape
+    if args.dtype == "bf16" and shape == "star2d1r":
+        shape = "box3d1r"  # the bf16 configuration of BASELINE.json
     dims = tuple(args.size) if args.size else DEFAULT_SIZES[shape]
+    bf16 = args.dtype == "bf16"
+    tdtype = torch.bfloat16 if bf16 else torch.float64
+    esize = 2 if bf16 else 8
     K, W = args.steps, args.warmup
     opts = dict(kv.split("=") for kv in args.option)
     variant = {"auto": L.VARIANT_AUTO, "direct": L.VARIANT_DIRECT, "mfma": L.VARIANT_MFMA}[args.variant]
 
     # taps: the operator's own; if the run is longer than the fp64 range allows use the normalised taps
     weights = L.effective_weights(shape)
-    normalised = (K + W) > OVERFLOW_STEPS.get(shape, 100)
+    normalised = (K + W) > (20 if bf16 else OVERFLOW_STEPS.get(shape, 100))
     if normalised:
         weights = weights / weights.sum()
 
@@ -159,14 +165,14 @@ def main():
         torch.cuda.synchronize()
 
     if world == 1:
-        plan = L.Plan(shape, dims).set_weights(weights)
+        plan = L.Plan(shape, dims, dtype=args.dtype).set_weights(weights)
         if variant != L.VARIANT_AUTO:
             plan.set_variant(variant)
         for k, v in opts.items():
             plan.set_option(k, int(v))
         ps = plan.padded_shape
-        src0 = torch.randint(0, 100, ps, generator=gen, device=dev).to(torch.float64)
-        b0, b1 = src0.clone(), torch.zeros(ps, dtype=torch.float64, device=dev)
+        src0 = torch.randint(0, 100, ps, generator=gen, device=dev).to(tdtype)
+        b0, b1 = src0.clone(), torch.zeros(ps, dtype=tdtype, device=dev)
         run = lambda n: plan.run(b0, b1, n)  # noqa: E731
         kernel = plan.kernel_name
         local_points = 1
@@ -177,13 +183,13 @@ def main():
             b0.copy_(src0)
             b1.zero_()
     else:
-        drv = slab.SlabDriver(shape, dims, device=dev, weights=weights)
+        drv = slab.SlabDriver(shape, dims, device=dev, weights=weights, dtype=args.dtype)
         plan = drv.stepper.plan
         if variant != L.VARIANT_AUTO:
             plan.set_variant(variant)
         for k, v in opts.items():
             plan.set_option(k, int(v))
-        src0 = torch.randint(0, 100, drv.local_padded_shape, generator=gen, device=dev).to(torch.float64)
+        src0 = torch.randint(0, 100, drv.local_padded_shape, generator=gen, device=dev).to(tdtype)
         run = lambda n: drv.run(n)  # noqa: E731
         kernel = plan.kernel_name
         local_points = drv.layout.own
@@ -223,7 +229,7 @@ def main():
         spl = 2 if drv.fused else 1
     launches = max(1, K // spl) if spl > 1 else K
     launch_s = ev_ms / 1e3 / launches  # average launch duration on the launch stream (HIP events)
-    bytes_per_launch = local_points * 16.0 * (K / launches)
+    bytes_per_launch = local_points * 2.0 * esize * (K / launches)
     achieved = bytes_per_launch / launch_s / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -245,10 +251,10 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f64",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": f"{shape} {'x'.join(map(str, dims))} fp64, {K} sweeps (lorastencil_{len(dims)}d {shape} "
+                "workload": f"{shape} {'x'.join(map(str, dims))} {'bf16' if bf16 else 'fp64'}, {K} sweeps (lorastencil_{len(dims)}d {shape} "
                             f"{' '.join(map(str, dims))} {K})",
                 "parallelism": (f"row-slabs x{world}, ghost {drv.layout.ghost} rows refreshed every "
                                 f"{drv.exchange_every} launches") if world > 1 else "single GPU",
@@ -270,7 +276,7 @@ def main():
                 "applications_per_launch": spl,
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not bf16:
             res["cpu_baseline"] = cpu_baseline(shape, dims, args.cpu_seconds)
         print(json.dumps(res), flush=True)
     if world > 1:

@@ -52,7 +52,9 @@ typedef enum lora_shape {
 } lora_shape;
 
 typedef enum lora_dtype {
-    LORA_F64 = 0 /* the reference's only type (DATA_TYPE double, 2d_utils.h:1) */
+    LORA_F64 = 0, /* the reference's only type (DATA_TYPE double, 2d_utils.h:1) */
+    LORA_BF16 = 1 /* NEW (no reference counterpart): bf16 storage, fp32 accumulation in tap order, one
+                     round-to-nearest-even per sweep; 3D shapes only, innermost extent a multiple of 8 */
 } lora_dtype;
 
 /* Kernel formulation of one sweep (B: lora_plan_set_variant). */
@@ -124,6 +126,10 @@ typedef struct lora_run_info {
  * lines; `info` may be NULL. */
 int lora_run_host(int shape, const double *in, double *out, const double *params, int times, const int *dims,
                   int quiet, lora_run_info *info);
+/* The same for a given element type: `in` / `out` are padded host arrays of doubles (LORA_F64) or of bf16 bit
+ * patterns in uint16_t (LORA_BF16). */
+int lora_run_host_dtype(int shape, int dtype, const void *in, void *out, const double *params, int times,
+                        const int *dims, int quiet, lora_run_info *info);
 /* lora_run_info of the last group-A call on this thread (what the CLIs print after the reference's lines). */
 int lora_last_run_info(lora_run_info *info);
 
@@ -183,6 +189,10 @@ int lora_effective_weights(int shape, const double *params, double *weights);
  * `residual_max` (nullable) receives max |params - sum_{t<3} u_t v_t^T|: the part the
  * reference silently drops. */
 int lora_factorize_7x7(const double *params, double *u, double *v, double *residual_max);
+
+/* bf16 <-> double on the host (round-to-nearest-even; bf16 values are bit patterns in uint16_t). */
+void lora_f64_to_bf16(const double *src, uint16_t *dst, size_t count);
+void lora_bf16_to_f64(const uint16_t *src, double *dst, size_t count);
 
 /* glibc rand() stream (TYPE_3, seed 1 = the reference's un-seeded rand()) so that inputs are
  * identical on any libc.  Fill = (double)(rand() % mod): 1d/main.cu:105-109 (mod 10000),

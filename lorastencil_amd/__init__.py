@@ -18,6 +18,7 @@ from .ops import (  # noqa: F401
     device_count,
     effective_weights,
     factorize_7x7,
+    from_bf16,
     gpu_1d1r,
     gpu_1d2r,
     gpu_box_2d3r,
@@ -29,6 +30,7 @@ from .ops import (  # noqa: F401
     padded_shape,
     reference_input,
     run_host,
+    to_bf16,
 )
 
 VARIANT_AUTO, VARIANT_DIRECT, VARIANT_MFMA = _lib.VARIANT_AUTO, _lib.VARIANT_DIRECT, _lib.VARIANT_MFMA

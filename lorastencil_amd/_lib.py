@@ -21,6 +21,7 @@ LORA_ENOMEM = -4
 LORA_ENODEVICE = -5
 
 F64 = 0
+BF16 = 1
 VARIANT_AUTO, VARIANT_DIRECT, VARIANT_MFMA = 0, 1, 2
 
 _dp = ctypes.POINTER(ctypes.c_double)
@@ -70,7 +71,11 @@ SIGNATURES = {
     "lora_gpu_star_3d1r": (ctypes.c_int, [_dp, _dp, _dp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "lora_run_host": (ctypes.c_int, [ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _ip, ctypes.c_int,
                                      ctypes.POINTER(RunInfo)]),
+    "lora_run_host_dtype": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _dp, ctypes.c_int, _ip, ctypes.c_int,
+                                           ctypes.POINTER(RunInfo)]),
     "lora_last_run_info": (ctypes.c_int, [ctypes.POINTER(RunInfo)]),
+    "lora_f64_to_bf16": (None, [_dp, ctypes.POINTER(ctypes.c_uint16), ctypes.c_size_t]),
+    "lora_bf16_to_f64": (None, [ctypes.POINTER(ctypes.c_uint16), _dp, ctypes.c_size_t]),
     "lora_plan_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int, _ip, _dp]),
     "lora_plan_set_weights": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),
     "lora_plan_get_weights": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),

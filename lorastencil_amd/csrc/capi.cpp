@@ -156,7 +156,7 @@ void plan_refresh(Plan &p) {
             if ((dz != 1) + (dy != 1) + (dx != 1) > 1) star = false;
         }
         p.tapset = star ? TAPS3D_STAR : TAPS3D_BOX;
-        p.kernel_name = kernel_name_3d(p);
+        p.kernel_name = (p.dtype == LORA_BF16) ? kernel_name_3d_bf16(p) : kernel_name_3d(p);
     } else {
         p.tapset = 0;
         p.kernel_name = kernel_name_1d(p);
@@ -182,7 +182,9 @@ static int step_region(Plan &p, const void *d_in, void *d_out, int begin, int en
     const double *in = static_cast<const double *>(d_in);
     double *out = static_cast<double *>(d_out);
     hipError_t e;
-    if (p.ndim == 1)
+    if (p.dtype == LORA_BF16)
+        e = launch_3d_bf16(p, d_in, d_out, begin, end, s);
+    else if (p.ndim == 1)
         e = launch_1d(p, in, out, begin, end, s);
     else if (p.ndim == 2)
         e = (p.variant == LORA_VARIANT_MFMA) ? launch_2d_mfma(p, in, out, begin, end, s)
@@ -237,7 +239,15 @@ int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, con
     if (!out || !dims) return LORA_EINVAL;
     *out = nullptr;
     const int nd = lora::shape_ndim(shape);
-    if (nd == 0 || dtype != LORA_F64) return LORA_EINVAL;
+    if (nd == 0 || (dtype != LORA_F64 && dtype != LORA_BF16)) return LORA_EINVAL;
+    if (dtype == LORA_BF16 && nd != 3) {
+        g_last_error = "bf16 is implemented for the 3D shapes only";
+        return LORA_EUNSUPPORTED;
+    }
+    if (dtype == LORA_BF16 && (dims[2] & 7)) {
+        g_last_error = "bf16 grids need an innermost extent that is a multiple of 8";
+        return LORA_EUNSUPPORTED;
+    }
     for (int d = 0; d < nd; ++d)
         if (dims[d] <= 0) return LORA_EINVAL;
     // 2D/3D rows are read and written in 16-byte pieces: the innermost extent must be even
@@ -361,7 +371,7 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
 
 size_t lora_plan_padded_bytes(const lora_plan *plan) {
     if (!plan) return 0;
-    return lora_padded_count(plan->p.shape, plan->p.dims) * sizeof(double);
+    return lora_padded_count(plan->p.shape, plan->p.dims) * (plan->p.dtype == LORA_BF16 ? 2 : sizeof(double));
 }
 
 const char *lora_plan_kernel_name(const lora_plan *plan) { return plan ? plan->p.kernel_name.c_str() : ""; }
@@ -470,13 +480,18 @@ struct DeviceBuffers {
 
 int lora_run_host(int shape, const double *in, double *out, const double *params, int times, const int *dims,
                   int quiet, lora_run_info *info) {
+    return lora_run_host_dtype(shape, LORA_F64, in, out, params, times, dims, quiet, info);
+}
+
+int lora_run_host_dtype(int shape, int dtype, const void *in, void *out, const double *params, int times,
+                        const int *dims, int quiet, lora_run_info *info) {
     if (!in || !out || !dims || times < 0) return LORA_EINVAL;
     if (lora_device_count() <= 0) {
         g_last_error = "no HIP device visible";
         return LORA_ENODEVICE;
     }
     lora_plan *plan = nullptr;
-    int rc = lora_plan_create(&plan, shape, LORA_F64, dims, params);
+    int rc = lora_plan_create(&plan, shape, dtype, dims, params);
     if (rc != LORA_OK) return rc;
     struct PlanGuard {
         lora_plan *p;
@@ -485,7 +500,8 @@ int lora_run_host(int shape, const double *in, double *out, const double *params
 
     using clock = std::chrono::steady_clock;
     const size_t count = lora_padded_count(shape, dims);
-    const size_t bytes = count * sizeof(double);
+    const size_t esize = (dtype == LORA_BF16) ? 2 : sizeof(double);
+    const size_t bytes = count * esize;
     DeviceBuffers dev;
     const auto t_total0 = clock::now();
     LORA_HIP_TRY(hipMalloc(&dev.b[0], bytes));
@@ -506,7 +522,7 @@ int lora_run_host(int shape, const double *in, double *out, const double *params
     const auto t1 = clock::now();
 
     // 1D copies all but the last element (1d/gpu_1r.cu:134)
-    const size_t copy_bytes = (plan->p.ndim == 1) ? bytes - sizeof(double) : bytes;
+    const size_t copy_bytes = (plan->p.ndim == 1) ? bytes - esize : bytes;
     LORA_HIP_TRY(hipMemcpy(out, dev.b[times % 2], copy_bytes, hipMemcpyDeviceToHost));
     const auto t_total1 = clock::now();
 
@@ -520,7 +536,7 @@ int lora_run_host(int shape, const double *in, double *out, const double *params
     ri.total_seconds = std::chrono::duration<double>(t_total1 - t_total0).count();
     ri.gstencils = points * times / ri.sweep_seconds / 1e9;
     ri.gstencils_refconv = ri.gstencils * F;
-    ri.hbm_gbs = points * times * 2.0 * sizeof(double) / ri.sweep_seconds / 1e9;
+    ri.hbm_gbs = points * times * 2.0 * esize / ri.sweep_seconds / 1e9;
     ri.variant = plan->p.variant;
     ri.steps_per_launch = plan->p.steps_per_launch;
     lora::g_last_info = ri;
@@ -534,6 +550,28 @@ int lora_run_host(int shape, const double *in, double *out, const double *params
         std::fflush(stdout);
     }
     return LORA_OK;
+}
+
+// host-side bf16 conversion (round-to-nearest-even; NaN stays a quiet NaN)
+static uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t) ((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t) (u >> 16);
+}
+
+void lora_f64_to_bf16(const double *src, uint16_t *dst, size_t count) {
+    for (size_t i = 0; i < count; ++i) dst[i] = f32_to_bf16_bits((float) src[i]);
+}
+
+void lora_bf16_to_f64(const uint16_t *src, double *dst, size_t count) {
+    for (size_t i = 0; i < count; ++i) {
+        const uint32_t u = (uint32_t) src[i] << 16;
+        float f;
+        std::memcpy(&f, &u, 4);
+        dst[i] = f;
+    }
 }
 
 int lora_last_run_info(lora_run_info *info) {

@@ -8,6 +8,7 @@
 //   --check            run the reference's CHECK_ERROR self-check (one sweep against a naive CPU loop, 1e-7 abs)
 //   --fill=random|index|ones   the reference's FILL_RANDOM / FILL_INDEX / default fills (compile-time macros there)
 //   --no-extra         print nothing beyond the reference's own lines
+//   --dtype=bf16       (lorastencil_3d only) store the grid in bf16, accumulate in fp32 (BASELINE config 5; new)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -120,7 +121,7 @@ int main(int argc, char *argv[]) {
         return 1;
     }
 
-    bool check = false, extra = true;
+    bool check = false, extra = true, bf16 = false;
     Fill fill = Fill::Random;
     for (int i = kDim + 3; i < argc; ++i) {
         const std::string a = argv[i];
@@ -134,6 +135,10 @@ int main(int argc, char *argv[]) {
             fill = Fill::Index;
         else if (a == "--fill=ones")
             fill = Fill::Ones;
+        else if (a == "--dtype=f64")
+            bf16 = false;
+        else if (a == "--dtype=bf16" && kDim == 3)
+            bf16 = true;
         else {
             std::cerr << "Unknown option: " << a << "\n";
             return 1;
@@ -170,6 +175,18 @@ int main(int argc, char *argv[]) {
         std::cout << argv[1] << std::endl;
     }
 
+    if (bf16) {
+        // values 0..99 are exact in bf16; the operator prints the reference's three lines itself
+        std::vector<uint16_t> in16(count), out16(count, 0);
+        lora_f64_to_bf16(matrix.data(), in16.data(), count);
+        const int rc = lora_run_host_dtype(shape, LORA_BF16, in16.data(), out16.data(), params, times, dims, 0, nullptr);
+        if (rc != LORA_OK) {
+            std::printf("LoRAStencil HIP Error: %s %s\n", lora_strerror(rc), lora_last_error());
+            return 1;
+        }
+        lora_bf16_to_f64(out16.data(), output.data(), count);
+        check = false;  // the fp64 self-check tolerance (1e-7) does not apply to bf16 storage
+    } else
     switch (shape) {
         case LORA_1D1R:
             gpu_1d1r(matrix.data(), output.data(), params, times, dims[0]);
@@ -199,7 +216,8 @@ int main(int argc, char *argv[]) {
         lora_run_info ri;
         if (lora_last_run_info(&ri) == LORA_OK && ri.sweep_seconds > 0) {
             std::printf("GStencils/s (per kernel application, F=1) = %f\n", ri.gstencils);
-            std::printf("Algorithmic HBM traffic = %f GB/s (%.1f%% of 8000 GB/s)\n", ri.hbm_gbs, ri.hbm_gbs / 80.0);
+            std::printf("Algorithmic HBM traffic = %f GB/s (%.1f%% of 8000 GB/s)%s\n", ri.hbm_gbs, ri.hbm_gbs / 80.0,
+                        bf16 ? " [bf16 storage]" : "");
             std::printf("Total incl. transfers = %f s\n", ri.total_seconds);
         }
     }

@@ -77,6 +77,8 @@ hipError_t launch_2d_fused2(const Plan &p, const double *in, double *out, int be
 hipError_t launch_halo_ring_2d(const Plan &p, double *dst, const double *src, hipStream_t s);
 const char *kernel_name_2d_fused2(const Plan &p);
 hipError_t launch_3d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+hipError_t launch_3d_bf16(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s);
+const char *kernel_name_3d_bf16(const Plan &p);
 
 const char *kernel_name_1d(const Plan &p);
 const char *kernel_name_2d_direct(const Plan &p);

@@ -144,10 +144,47 @@ def reference_input(shape, dims, rng: GlibcRand | None = None) -> np.ndarray:
     return rng.fill(int(np.prod(ps)), 100).reshape(ps)
 
 
+DTYPES = {"f64": _lib.F64, "fp64": _lib.F64, "float64": _lib.F64, "bf16": _lib.BF16, "bfloat16": _lib.BF16}
+
+
+def dtype_id(dtype) -> int:
+    if isinstance(dtype, str):
+        return DTYPES[dtype]
+    return int(dtype)
+
+
+def to_bf16(a: np.ndarray) -> np.ndarray:
+    """float64 array -> bf16 bit patterns (uint16), round-to-nearest-even."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    out = np.empty(a.shape, dtype=np.uint16)
+    _lib.lib().lora_f64_to_bf16(_p(a), out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), a.size)
+    return out
+
+
+def from_bf16(a: np.ndarray) -> np.ndarray:
+    """bf16 bit patterns (uint16) -> float64 (exact)."""
+    a = np.ascontiguousarray(a, dtype=np.uint16)
+    out = np.empty(a.shape, dtype=np.float64)
+    _lib.lib().lora_bf16_to_f64(a.ctypes.data_as(ctypes.POINTER(ctypes.c_uint16)), _p(out), a.size)
+    return out
+
+
 # ---- group A: the reference's operators on host arrays -------------------------------------------------
 def run_host(shape, in_: np.ndarray, params=None, times: int = 1, quiet: bool = True, out: np.ndarray | None = None):
-    """Generic host-buffer operator.  Returns (out, RunInfo)."""
+    """Generic host-buffer operator.  Returns (out, RunInfo).  A uint16 input is taken as bf16 bit patterns."""
     sid = shape_id(shape)
+    if in_.dtype == np.uint16:
+        in_ = np.ascontiguousarray(in_)
+        h = halo(sid)
+        dims = [in_.shape[i] - 2 * h[i] for i in range(in_.ndim)]
+        if out is None:
+            out = np.zeros_like(in_)
+        pp = None if params is None else _p(np.ascontiguousarray(params, dtype=np.float64))
+        info = RunInfo()
+        check(_lib.lib().lora_run_host_dtype(sid, _lib.BF16, in_.ctypes.data, out.ctypes.data, pp, int(times),
+                                             _dims_arg(dims), int(quiet), ctypes.byref(info)),
+              f"lora_run_host_dtype({SHAPE_NAMES.get(sid, sid)}, bf16)")
+        return out, info
     in_ = np.ascontiguousarray(in_, dtype=np.float64)
     h = halo(sid)
     if in_.ndim != len(h):
@@ -213,14 +250,15 @@ class Plan:
     ``torch.cuda.Stream``, a raw ``hipStream_t`` or None (= torch's current stream).
     """
 
-    def __init__(self, shape, dims: Sequence[int], params=None):
+    def __init__(self, shape, dims: Sequence[int], params=None, dtype="f64"):
         self.shape = shape_id(shape)
+        self.dtype = dtype_id(dtype)
         self.dims = tuple(int(d) for d in dims)
         if len(self.dims) != ndim(self.shape):
             raise ValueError("wrong number of sizes for the shape")
         self._h = ctypes.c_void_p()
         pp = None if params is None else _p(np.ascontiguousarray(params, dtype=np.float64))
-        check(_lib.lib().lora_plan_create(ctypes.byref(self._h), self.shape, _lib.F64, _dims_arg(self.dims), pp),
+        check(_lib.lib().lora_plan_create(ctypes.byref(self._h), self.shape, self.dtype, _dims_arg(self.dims), pp),
               "lora_plan_create")
 
     def close(self):

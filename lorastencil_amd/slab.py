@@ -104,8 +104,8 @@ def slab_layout(shape, global_dims: Sequence[int], world_size: int, rank: int, m
 class HipStepper:
     """Product stepper: the HIP engine on the local array (own rows + ghost rows)."""
 
-    def __init__(self, layout: SlabLayout, params=None, weights=None):
-        self.plan = ops.Plan(layout.shape, layout.local_dims, params)
+    def __init__(self, layout: SlabLayout, params=None, weights=None, dtype="f64"):
+        self.plan = ops.Plan(layout.shape, layout.local_dims, params, dtype=dtype)
         if weights is not None:
             self.plan.set_weights(weights)
 
@@ -125,7 +125,8 @@ class SlabDriver:
 
     def __init__(self, shape, global_dims: Sequence[int], group=None, device=None, params=None, weights=None,
                  stepper_factory: Callable[[SlabLayout], object] | None = None, overlap: bool = True,
-                 exchange_every: int | None = None, fused: bool | None = None, boundary_rows: int | None = None):
+                 exchange_every: int | None = None, fused: bool | None = None, boundary_rows: int | None = None,
+                 dtype="f64"):
         self.group = group
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -138,7 +139,12 @@ class SlabDriver:
         radius = probe.radius0
         if fused is None:
             fused = (nd == 2)  # refined below by what the stepper supports
-        self._make_stepper = stepper_factory or (lambda lay: HipStepper(lay, params=params, weights=weights))
+        self.dtype = ops.dtype_id(dtype)
+        self.torch_dtype = torch.bfloat16 if self.dtype == ops.DTYPES["bf16"] else torch.float64
+        if self.dtype == ops.DTYPES["bf16"]:
+            fused = False  # the bf16 kernels are the 3D single-sweep ones
+        self._make_stepper = stepper_factory or (
+            lambda lay: HipStepper(lay, params=params, weights=weights, dtype=self.dtype))
         # thinnest slab of the decomposition bounds the ghost depth (neighbours supply ghost rows from own rows)
         thinnest = min(slab_layout(sid, global_dims, self.world_size, r).own for r in range(self.world_size))
         if exchange_every is None:
@@ -162,7 +168,7 @@ class SlabDriver:
         self.radius = radius
         self.overlap = overlap
         self.local_padded_shape = ops.padded_shape(sid, layout.local_dims)
-        self.buf = [torch.zeros(self.local_padded_shape, dtype=torch.float64, device=self.device) for _ in range(2)]
+        self.buf = [torch.zeros(self.local_padded_shape, dtype=self.torch_dtype, device=self.device) for _ in range(2)]
         if boundary_rows is None:
             boundary_rows = {1: 4096, 2: 32, 3: 1}[nd]
         self.strip = max(layout.ghost, min(boundary_rows, layout.own // 2))

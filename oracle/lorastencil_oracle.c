@@ -8,6 +8,7 @@
  */
 #include "lorastencil_oracle.h"
 
+#include <math.h>
 #include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
@@ -376,4 +377,65 @@ int oracle_run(int shape, const double *in, double *out, const double *params, i
     double w[49];
     if (oracle_effective_weights(shape, params, w) < 0) return -1;
     return oracle_run_weights(shape, in, out, w, times, dims, threads);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * bf16 storage, fp32 accumulation (NEW capability; parity unpinned by the reference, see header)
+ * ---------------------------------------------------------------------------------------- */
+uint16_t oracle_f32_to_bf16(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t) ((u >> 16) | 0x0040u); /* NaN stays a (quiet) NaN */
+    u += 0x7fffu + ((u >> 16) & 1u);                                               /* round to nearest even */
+    return (uint16_t) (u >> 16);
+}
+
+float oracle_bf16_to_f32(uint16_t b) {
+    const uint32_t u = (uint32_t) b << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+
+void oracle_step_3d_bf16(const uint16_t *in, uint16_t *out, const float *w, int heights, int rows, int cols,
+                         int threads) {
+    const int nt = pick_threads(threads);
+    (void) nt;
+    const ptrdiff_t plane = (ptrdiff_t) rows * cols;
+    ptrdiff_t off[27];
+    for (int k = 0; k < 27; k++) off[k] = (k / 9 - 1) * plane + ((k / 3) % 3 - 1) * (ptrdiff_t) cols + (k % 3 - 1);
+#pragma omp parallel for num_threads(nt) schedule(static) collapse(2) if (nt > 1)
+    for (int h = 1; h < heights - 1; h++) {
+        for (int row = 2; row < rows - 2; row++) {
+            for (int col = 4; col < cols - 4; col++) {
+                const uint16_t *c = in + h * plane + (ptrdiff_t) row * cols + col;
+                float s = 0.0f;
+                for (int k = 0; k < 27; k++) s = fmaf(w[k], oracle_bf16_to_f32(c[off[k]]), s);
+                out[h * plane + (ptrdiff_t) row * cols + col] = oracle_f32_to_bf16(s);
+            }
+        }
+    }
+}
+
+int oracle_run_bf16(int shape, const uint16_t *in, uint16_t *out, const double *w27, int times, const int *dims,
+                    int threads) {
+    if (shape_dim(shape) != 3 || times < 0) return -1;
+    const size_t count = oracle_padded_count(shape, dims);
+    float w[27];
+    for (int k = 0; k < 27; k++) w[k] = (float) w27[k];
+    uint16_t *buf[2];
+    buf[0] = (uint16_t *) malloc(count * sizeof(uint16_t));
+    buf[1] = (uint16_t *) calloc(count, sizeof(uint16_t));
+    if (!buf[0] || !buf[1]) {
+        free(buf[0]);
+        free(buf[1]);
+        return -1;
+    }
+    memcpy(buf[0], in, count * sizeof(uint16_t));
+    for (int i = 0; i < times; i++)
+        oracle_step_3d_bf16(buf[i % 2], buf[(i + 1) % 2], w, dims[0] + 2, dims[1] + 4, dims[2] + 8, threads);
+    memcpy(out, buf[times % 2], count * sizeof(uint16_t));
+    free(buf[0]);
+    free(buf[1]);
+    return 0;
 }

@@ -91,6 +91,18 @@ int oracle_run(int shape, const double *in, double *out, const double *params, i
 int oracle_run_weights(int shape, const double *in, double *out, const double *w, int times, const int *dims,
                        int threads);
 
+/* ---- bf16 storage (3D shapes).  PARITY UNPINNED: the reference has no reduced-precision path at all
+ * (SURVEY section 2 row 12), so there is nothing of its own to pin this against.  The contract restated here is the
+ * one the engine documents (kernels_3d_bf16.hip): bf16 values, fp32 taps, one fp32 fused multiply-add per tap in
+ * test_cpu's tap order (3d/main.cu:33-68) starting from 0, one round-to-nearest-even to bf16 per sweep; driver
+ * semantics as in oracle_run. */
+uint16_t oracle_f32_to_bf16(float f);
+float oracle_bf16_to_f32(uint16_t b);
+void oracle_step_3d_bf16(const uint16_t *in, uint16_t *out, const float *w27, int heights, int rows, int cols,
+                         int threads);
+int oracle_run_bf16(int shape, const uint16_t *in, uint16_t *out, const double *w27, int times, const int *dims,
+                    int threads);
+
 /* Padded element count of a shape/dims (1D n+8; 2D (m+8)(n+8); 3D (h+2)(m+4)(n+8)). */
 size_t oracle_padded_count(int shape, const int *dims);
 

@@ -71,6 +71,13 @@ def lib() -> ctypes.CDLL:
         L.oracle_padded_count.argtypes = [ctypes.c_int, _ip]
         L.oracle_padded_count.restype = ctypes.c_size_t
         L.oracle_max_threads.restype = ctypes.c_int
+        _u16 = ctypes.POINTER(ctypes.c_uint16)
+        L.oracle_f32_to_bf16.argtypes = [ctypes.c_float]
+        L.oracle_f32_to_bf16.restype = ctypes.c_uint16
+        L.oracle_step_3d_bf16.argtypes = [_u16, _u16, ctypes.POINTER(ctypes.c_float), ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int, ctypes.c_int]
+        L.oracle_run_bf16.argtypes = [ctypes.c_int, _u16, _u16, _dp, ctypes.c_int, _ip, ctypes.c_int]
+        L.oracle_run_bf16.restype = ctypes.c_int
         _lib = L
     return _lib
 
@@ -203,3 +210,32 @@ def run(shape, a: np.ndarray, times: int, params=None, weights=None, threads: in
 
 def max_threads() -> int:
     return lib().oracle_max_threads()
+
+
+# ---- bf16 storage (3D shapes; parity unpinned by the reference: it has no reduced-precision path) -------------
+def to_bf16(a: np.ndarray) -> np.ndarray:
+    """float -> bf16 bit patterns (uint16), round-to-nearest-even (numpy restatement of oracle_f32_to_bf16)."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32).astype(np.uint64)
+    nan = (u & 0x7FFFFFFF) > 0x7F800000
+    r = (u + 0x7FFF + ((u >> 16) & 1)) >> 16
+    r = np.where(nan, (u >> 16) | 0x40, r)
+    return r.astype(np.uint16)
+
+
+def from_bf16(b: np.ndarray) -> np.ndarray:
+    return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
+
+
+def run_bf16(shape, a_bits: np.ndarray, times: int, weights=None, threads: int = 1) -> np.ndarray:
+    """The 3D operator on bf16 bit patterns with the reference's driver semantics."""
+    sid = shape_id(shape)
+    a_bits = np.ascontiguousarray(a_bits, dtype=np.uint16)
+    w = effective_weights(sid) if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    h = halo(sid)
+    dims = (ctypes.c_int * 3)(*[a_bits.shape[i] - 2 * h[i] for i in range(3)])
+    out = np.zeros_like(a_bits)
+    u16 = ctypes.POINTER(ctypes.c_uint16)
+    rc = lib().oracle_run_bf16(sid, a_bits.ctypes.data_as(u16), out.ctypes.data_as(u16), _p(w), times, dims, threads)
+    if rc != 0:
+        raise ValueError("oracle_run_bf16 failed")
+    return out

@@ -87,6 +87,22 @@ def test_glibc_rand_fill_matches_oracle_and_golden(L):
         assert np.array_equal(L.reference_input(shape, tuple(g["dims"])), g["input"])
 
 
+def test_bf16_conversion_matches_oracle(L):
+    rng = np.random.default_rng(3)
+    x = np.concatenate([rng.standard_normal(20000) * 10.0 ** rng.uniform(-35, 35, 20000),
+                        [0.0, -0.0, np.inf, -np.inf, 257.0, 259.0, 3.3e38, 3.4e38, 1e-40]])
+    x = x.astype(np.float32).astype(np.float64)
+    assert np.array_equal(L.to_bf16(x), O.to_bf16(x))
+    b = L.to_bf16(x)
+    assert np.array_equal(L.from_bf16(b), O.from_bf16(b))
+    assert L.from_bf16(L.to_bf16(np.array([257.0, 259.0]))).tolist() == [256.0, 260.0]  # ties to even
+    with pytest.raises(L.LoraError):
+        L.Plan("star2d1r", (64, 128), dtype="bf16")  # bf16 is a 3D-only path
+    with pytest.raises(L.LoraError):
+        L.Plan("box3d1r", (8, 8, 12), dtype="bf16")  # innermost extent must be a multiple of 8
+    assert L.Plan("box3d1r", (8, 8, 16), dtype="bf16").kernel_name == "stencil3d_bf16_kernel"
+
+
 def test_shape_tables(L):
     from lorastencil_amd import _lib
 

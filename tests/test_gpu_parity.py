@@ -305,6 +305,57 @@ def test_random_real_weights_and_inputs(L, O, shape, dims):
         assert rel_err(got, exp) < 1e-13, f"{shape} t={t}"
 
 
+# ---------------------------------------------------------------------------------------------------------
+# bf16 storage (BASELINE config 5; new capability -- the oracle for it is unpinned by the reference)
+# ---------------------------------------------------------------------------------------------------------
+def plan_run_bf16(L, shape, bits, times, weights=None, options=None):
+    import torch
+
+    dims = (bits.shape[0] - 2, bits.shape[1] - 4, bits.shape[2] - 8)
+    plan = L.Plan(shape, dims, dtype="bf16")
+    if weights is not None:
+        plan.set_weights(weights)
+    for k, v in (options or {}).items():
+        plan.set_option(k, v)
+    b0 = torch.from_numpy(bits.view(np.int16).copy()).cuda().view(torch.bfloat16)
+    b1 = torch.zeros_like(b0)
+    plan.run(b0, b1, times)
+    torch.cuda.synchronize()
+    return (b0, b1)[times % 2].view(torch.int16).cpu().numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("shape", ["box3d1r", "star3d1r"])
+@pytest.mark.parametrize("dims", [(8, 16, 128), (9, 21, 264), (5, 3, 8), (20, 40, 520)])
+def test_bf16_sweeps_match_oracle_bit_exact(L, O, shape, dims):
+    """Same taps (fp32), same fused multiply-add order, one rounding to bf16 per sweep: identical bit patterns."""
+    bits = O.to_bf16(O.reference_input(shape, dims))
+    for t in (1, 2, 5):
+        assert np.array_equal(plan_run_bf16(L, shape, bits, t), O.run_bf16(shape, bits, t)), f"{shape} {dims} t={t}"
+    # normalised taps (SURVEY B7: the reference taps overflow bf16 at step ~23), all z-chunk lengths
+    w = O.effective_weights(shape)
+    w = w / w.sum()
+    exp = O.run_bf16(shape, bits, 12, weights=w)
+    assert np.isfinite(O.from_bf16(exp)).all()
+    for zc in (1, 4, 16):
+        assert np.array_equal(plan_run_bf16(L, shape, bits, 12, weights=w, options={"z_chunk": zc}), exp)
+
+
+def test_bf16_host_operator_and_random_taps(L, O):
+    rng = np.random.default_rng(11)
+    shape, dims = "box3d1r", (6, 10, 64)
+    bits = O.to_bf16(rng.standard_normal(O.padded_shape(shape, dims)))
+    out, info = L.run_host(shape, bits, times=3)
+    assert out.dtype == np.uint16 and np.array_equal(out, O.run_bf16(shape, bits, 3))
+    w = rng.standard_normal(27)
+    w /= np.abs(w).sum()
+    assert np.array_equal(plan_run_bf16(L, shape, bits, 4, weights=w), O.run_bf16(shape, bits, 4, weights=w))
+    # the bf16 result tracks the fp64 one to bf16 precision
+    a = O.from_bf16(bits)
+    ref = O.run(shape, a, 3, weights=O.effective_weights(shape) / 36.0)
+    got = O.from_bf16(plan_run_bf16(L, shape, bits, 3, weights=O.effective_weights(shape) / 36.0))
+    assert rel_err(O.interior(shape, got), O.interior(shape, ref)) < 3 * 2.0 ** -8
+
+
 def test_params_are_honoured_like_the_reference(L, O):
     rng = np.random.default_rng(5)
     # star2d1r / star3d1r ignore params; star2d3r reads the centre row and column only; box3d1r reads params[0..2]

@@ -55,6 +55,72 @@ class OracleStepper:
         d[inner] = out[inner]
 
 
+class OracleStepperBf16:
+    """bf16 stand-in for HipStepper (tests only): tensors are torch.bfloat16, the oracle works on bit patterns."""
+
+    wants_fused = False
+
+    def __init__(self, layout, weights):
+        self.shape = layout.shape
+        self.w = np.ascontiguousarray(weights, dtype=np.float32)
+        self.calls = {"step": 0, "step2": 0}
+
+    def step_region(self, src, dst, begin, end):
+        import ctypes
+
+        from oracle import oracle as O
+
+        self.calls["step"] += 1
+        if end <= begin:
+            return
+        s = np.ascontiguousarray(src.view(torch.int16).numpy().view(np.uint16)[begin:end + 2])
+        out = np.zeros_like(s)
+        u16 = ctypes.POINTER(ctypes.c_uint16)
+        O.lib().oracle_step_3d_bf16(s.ctypes.data_as(u16), out.ctypes.data_as(u16),
+                                    self.w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), *s.shape, 1)
+        d = dst.view(torch.int16).numpy().view(np.uint16)[begin:end + 2]
+        d[1:-1, 2:-2, 4:-4] = out[1:-1, 2:-2, 4:-4]
+
+
+def _worker_bf16(rank, world, port, shape, dims, times, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lorastencil_amd import slab
+        from oracle import oracle as O
+
+        bits = O.to_bf16(O.reference_input(shape, dims))
+        w = O.effective_weights(shape)
+        drv = slab.SlabDriver(shape, dims, device="cpu", dtype="bf16", exchange_every=2,
+                              stepper_factory=lambda lay: OracleStepperBf16(lay, w))
+        drv.load_global(torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16))
+        drv.run(times)
+        full = drv.gather_global(0)
+        if rank == 0:
+            q.put(full.view(torch.int16).numpy().view(np.uint16))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bf16_slabs_equal_single_rank(engine_built):
+    from oracle import oracle as O
+
+    shape, dims, times, world = "box3d1r", (12, 6, 16), 5, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bf16, args=(r, world, port, shape, dims, times, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    bits = O.to_bf16(O.reference_input(shape, dims))
+    assert np.array_equal(got, O.run_bf16(shape, bits, times))
+
+
 def _worker(rank, world, port, shape, dims, times, overlap, q, fused=None, exchange_every=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
