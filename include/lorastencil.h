@@ -33,7 +33,7 @@ extern "C" {
 /* ---- status codes ---------------------------------------------------------------------- */
 #define LORA_OK 0
 #define LORA_EINVAL (-1)       /* bad shape / null pointer / negative size               */
-#define LORA_EUNSUPPORTED (-2) /* size the kernels cannot take (e.g. odd innermost extent) */
+#define LORA_EUNSUPPORTED (-2) /* size/dtype/variant combination the kernels cannot take       */
 #define LORA_EHIP (-3)         /* a HIP runtime call failed (see lora_last_error())        */
 #define LORA_ENOMEM (-4)
 #define LORA_ENODEVICE (-5) /* no HIP device visible: the engine has NO CPU fallback     */

@@ -140,12 +140,17 @@ void plan_refresh(Plan &p) {
         // (16384^2 / 8192^2, profiles/r01_sweep_fused_rows.jsonl: 25 taps 602 vs 352 GStencils/s, 13 taps 649 vs
         // 345, 49 taps 400 vs 350); the light 13-tap star prefers the small tile (more workgroups per CU), the
         // FMA-heavier sets the tall one (less recomputed halo)
-        if (p.variant == LORA_VARIANT_MFMA)
+        if (p.generic) {
+            p.variant = LORA_VARIANT_DIRECT;
+            p.lowrank_valid = false;
+        }
+        if (p.variant == LORA_VARIANT_MFMA || p.generic)
             p.steps_per_launch = 1;
         else
             p.steps_per_launch = p.steps_per_launch_req == 0 ? 2 : p.steps_per_launch_req;
         p.fused_rows = p.fused_rows_req ? p.fused_rows_req : (p.tapset == TAPS2D_STAR ? 6 : 10);
-        p.kernel_name = (p.variant == LORA_VARIANT_MFMA)
+        p.kernel_name = p.generic ? kernel_name_generic(p)
+                        : (p.variant == LORA_VARIANT_MFMA)
                             ? kernel_name_2d_mfma(p)
                             : (p.steps_per_launch == 2 ? kernel_name_2d_fused2(p) : kernel_name_2d_direct(p));
     } else if (p.ndim == 3) {
@@ -156,7 +161,7 @@ void plan_refresh(Plan &p) {
             if ((dz != 1) + (dy != 1) + (dx != 1) > 1) star = false;
         }
         p.tapset = star ? TAPS3D_STAR : TAPS3D_BOX;
-        p.kernel_name = (p.dtype == LORA_BF16) ? kernel_name_3d_bf16(p) : kernel_name_3d(p);
+        p.kernel_name = (p.dtype == LORA_BF16) ? kernel_name_3d_bf16(p) : (p.generic ? kernel_name_generic(p) : kernel_name_3d(p));
     } else {
         p.tapset = 0;
         p.kernel_name = kernel_name_1d(p);
@@ -184,6 +189,8 @@ static int step_region(Plan &p, const void *d_in, void *d_out, int begin, int en
     hipError_t e;
     if (p.dtype == LORA_BF16)
         e = launch_3d_bf16(p, d_in, d_out, begin, end, s);
+    else if (p.generic)
+        e = (p.ndim == 2) ? launch_2d_generic(p, in, out, begin, end, s) : launch_3d_generic(p, in, out, begin, end, s);
     else if (p.ndim == 1)
         e = launch_1d(p, in, out, begin, end, s);
     else if (p.ndim == 2)
@@ -250,8 +257,10 @@ int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, con
     }
     for (int d = 0; d < nd; ++d)
         if (dims[d] <= 0) return LORA_EINVAL;
-    // 2D/3D rows are read and written in 16-byte pieces: the innermost extent must be even
-    if (nd >= 2 && (dims[nd - 1] & 1)) {
+    // 2D/3D rows are read and written in 16-byte pieces by the tiled kernels; an odd innermost extent falls back to
+    // the generic one-thread-per-point kernels (fp64 only)
+    const bool odd_inner = nd >= 2 && (dims[nd - 1] & 1);
+    if (odd_inner && dtype != LORA_F64) {
         g_last_error = "innermost extent must be even";
         return LORA_EUNSUPPORTED;
     }
@@ -271,6 +280,7 @@ int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, con
     }
     lora::effective_weights(shape, params, p.w);
     p.variant = LORA_VARIANT_DIRECT;
+    p.generic = odd_inner;
     if (nd == 3) {
         // enough workgroups to fill 256 CUs a few times over, chunks as long as that allows
         const long tiles = (long) ((dims[2] + 127) / 128) * ((dims[1] + 15) / 16);
@@ -333,7 +343,7 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         p.fused_rows_req = value;
     } else if (!std::strcmp(key, "steps_per_launch")) {
         if (value < 0 || value > 2) return LORA_EINVAL;
-        if (value == 2 && (p.ndim != 2 || p.variant != LORA_VARIANT_DIRECT)) return LORA_EUNSUPPORTED;
+        if (value == 2 && (p.ndim != 2 || p.variant != LORA_VARIANT_DIRECT || p.generic)) return LORA_EUNSUPPORTED;
         p.steps_per_launch_req = value;
         if (p.ndim != 2) p.steps_per_launch = 1;
     } else {
@@ -391,7 +401,7 @@ int lora_plan_step(lora_plan *plan, const void *d_in, void *d_out, void *stream)
 int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream) {
     if (!plan) return LORA_EINVAL;
     Plan &p = plan->p;
-    if (p.ndim != 2 || p.variant != LORA_VARIANT_DIRECT) return LORA_EUNSUPPORTED;
+    if (p.ndim != 2 || p.variant != LORA_VARIANT_DIRECT || p.generic) return LORA_EUNSUPPORTED;
     if (int rc = lora::check_buffers(d_in, d_out)) return rc;
     if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
     const hipError_t e = lora::launch_2d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),

@@ -59,6 +59,7 @@ struct Plan {
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
     int steps_per_launch_req = 0;  // 0 = auto (fused for the diamond / star tap sets), 1, 2
     int steps_per_launch = 1;      // resolved
+    bool generic = false;  // odd innermost extent: rows are only 8-byte aligned, the tiled kernels do not apply
     bool lowrank_valid = false;
     LowRank2D lowrank{};
     std::string kernel_name;
@@ -77,6 +78,10 @@ hipError_t launch_2d_fused2(const Plan &p, const double *in, double *out, int be
 hipError_t launch_halo_ring_2d(const Plan &p, double *dst, const double *src, hipStream_t s);
 const char *kernel_name_2d_fused2(const Plan &p);
 hipError_t launch_3d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+// any size, any taps (odd innermost extents): one thread per point
+hipError_t launch_2d_generic(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+hipError_t launch_3d_generic(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+const char *kernel_name_generic(const Plan &p);
 hipError_t launch_3d_bf16(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s);
 const char *kernel_name_3d_bf16(const Plan &p);
 

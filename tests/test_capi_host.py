@@ -115,8 +115,8 @@ def test_shape_tables(L):
 
 
 def test_plan_validation(L):
-    with pytest.raises(L.LoraError):
-        L.Plan("star2d1r", (64, 127))  # odd innermost extent: rejected, not mis-computed
+    assert L.Plan("star2d1r", (64, 127)).kernel_name == "stencil2d_generic_kernel"  # odd extent: generic fallback
+    assert L.Plan("box3d1r", (4, 4, 5)).kernel_name == "stencil3d_generic_kernel"
     with pytest.raises(L.LoraError):
         L.Plan("star2d1r", (0, 128))
     p = L.Plan("star2d1r", (64, 128))

@@ -143,6 +143,18 @@ def test_ragged_sizes_match_oracle(L, O, shape, dims):
         assert np.array_equal(got, exp), f"{shape} {dims} t={t}"
 
 
+@pytest.mark.parametrize("shape,dims", [("star2d1r", (33, 65)), ("box2d3r", (20, 131)), ("star2d3r", (1, 1)),
+                                        ("star3d1r", (7, 9, 33)), ("box3d1r", (3, 2, 1))])
+def test_odd_innermost_extents_use_the_generic_kernels(L, O, shape, dims):
+    a = O.reference_input(shape, dims)
+    plan = L.Plan(shape, dims)
+    assert "generic" in plan.kernel_name
+    for t in (1, 4, 5):
+        assert np.array_equal(plan_run(L, shape, a, t), O.run(shape, a, t)), f"{shape} {dims} t={t}"
+    out, _ = L.run_host(shape, a, times=2)
+    assert np.array_equal(out, O.run(shape, a, 2))
+
+
 @pytest.mark.parametrize("rpt", [4, 8, 16])
 @pytest.mark.parametrize("panel", [1, 3, 8, 64])
 def test_2d_kernel_options_do_not_change_results(L, O, rpt, panel):
