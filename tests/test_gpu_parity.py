@@ -536,3 +536,70 @@ def test_reference_harness_self_check_on_this_engine(L, dim, args):
     assert "Comparing naive and lora" in out and lines[-1] == "Correct!"
     i = lines.index("Comparing naive and lora")
     assert lines[i + 1:] == ["Correct!"], "the reference's self-check printed mismatches:\n" + "\n".join(lines[i:i + 10])
+
+
+# ---------------------------------------------------------------------------------------------------------
+# multi-rank slabs with the REAL HIP stepper: three ranks share this one GPU and exchange ghost zones over gloo
+# (RCCL itself needs one GPU per rank; everything else of the N > 1 product path runs here)
+# ---------------------------------------------------------------------------------------------------------
+def _slab_rank(rank, world, port, shape, dims, times, every, dtype, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from lorastencil_amd import slab
+        from oracle import oracle as O
+
+        a = O.reference_input(shape, dims)
+        drv = slab.SlabDriver(shape, dims, device="cuda:0", exchange_every=every, dtype=dtype)
+        if dtype == "bf16":
+            bits = O.to_bf16(a)
+            drv.load_global(torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16))
+        else:
+            drv.load_global(a)
+        drv.run(times // 2)
+        drv.run(times - times // 2)
+        full = drv.gather_global(0)
+        if rank == 0:
+            res = full.view(torch.int16).numpy().view(np.uint16) if dtype == "bf16" else full.numpy()
+            q.put((res, drv.fused, drv.layout.ghost))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape,dims,times,every,dtype", [
+    ("star2d1r", (384, 256), 9, 2, "f64"),     # fused pairs + odd tail, 12-row ghost zones
+    ("star2d1r", (768, 384), 16, 4, "f64"),    # the bench configuration: 24-row ghost zones, refresh every 4 launches
+    ("box2d3r", (300, 130), 6, 3, "f64"),
+    ("star3d1r", (24, 20, 64), 7, 2, "f64"),
+    ("box3d1r", (24, 20, 64), 6, 3, "bf16"),
+])
+def test_three_rank_slabs_on_one_gpu_equal_single_rank(L, O, shape, dims, times, every, dtype):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_slab_rank, args=(r, world, port, shape, dims, times, every, dtype, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got, fused, ghost = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    a = O.reference_input(shape, dims)
+    if dtype == "bf16":
+        exp = O.run_bf16(shape, O.to_bf16(a), times)
+    else:
+        exp = O.run(shape, a, times)
+    assert np.array_equal(got, exp)
+    assert fused == (len(dims) == 2 and dtype == "f64")
+    assert ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * (2 if fused else 1) * every
