@@ -338,6 +338,11 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         p.nt_store = value ? 1 : 0;
     } else if (!std::strcmp(key, "persistent")) {
         p.persistent = value ? 1 : 0;
+    } else if (!std::strcmp(key, "lds_dma")) {
+        p.lds_dma = value ? 1 : 0;
+    } else if (!std::strcmp(key, "cols_per_lane")) {
+        if (value != 4 && value != 8) return LORA_EINVAL;
+        p.cols_per_lane = value;
     } else if (!std::strcmp(key, "fused_rows")) {
         if (value != 0 && value != 6 && value != 8 && value != 10) return LORA_EINVAL;
         p.fused_rows_req = value;
@@ -366,6 +371,10 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.nt_store;
     else if (!std::strcmp(key, "persistent"))
         *value = p.persistent;
+    else if (!std::strcmp(key, "lds_dma"))
+        *value = p.lds_dma;
+    else if (!std::strcmp(key, "cols_per_lane"))
+        *value = p.cols_per_lane;
     else if (!std::strcmp(key, "fused_rows"))
         *value = p.fused_rows;
     else if (!std::strcmp(key, "steps_per_launch"))

@@ -55,6 +55,8 @@ struct Plan {
     int nt_store = 0;         // 2D: non-temporal output stores
     int fused_rows_req = 0;   // 0 = auto, else 6 / 8 / 10
     int fused_rows = 8;       // 2D fused: intermediate rows per wave (tile = 4x this - 6 output rows), resolved
+    int cols_per_lane = 4;    // 3D bf16: 4 (512-byte row pieces per wave) or 8 (1 KiB)
+    int lds_dma = 0;          // 3D bf16: global_load_lds ring, two planes ahead (hand-counted vmcnt)
     int persistent = 0;       // 2D fused: persistent workgroups with register prefetch of the next tile
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
     int steps_per_launch_req = 0;  // 0 = auto (fused for the diamond / star tap sets), 1, 2

@@ -27,10 +27,19 @@ namespace {
 typedef unsigned short u16;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 
-constexpr int kTileW = 256;              // output columns per tile: 64 lanes x 4
-constexpr int kLdsW = kTileW + 8;        // staged bf16 columns
-constexpr int kChunksPerRow = kLdsW / 8; // 16-byte pieces per staged row
+// Geometry for CPL columns per lane (4 or 8): a wave covers 64 x CPL columns, i.e. 512 B or 1 KiB row pieces.
+template <int CPL>
+struct Geo {
+    static constexpr int kTileW = 64 * CPL;         // output columns per tile
+    static constexpr int kLdsW = kTileW + 8;        // staged bf16 columns
+    static constexpr int kChunksPerRow = kLdsW / 8; // 16-byte pieces per staged row
+    static constexpr int kWinDwords = (CPL + 8) / 2; // window of a lane: elements 0 .. CPL+7 (own: 4 .. CPL+3)
+};
+constexpr int kTileW = Geo<4>::kTileW;   // the LDS-DMA ring kernel below is the 4-column form
+constexpr int kLdsW = Geo<4>::kLdsW;
+constexpr int kChunksPerRow = Geo<4>::kChunksPerRow;
 
 struct Taps27f {
     float w[27];
@@ -50,6 +59,8 @@ __device__ __forceinline__ int xcd_contiguous(int b, int nb) {
 
 __device__ __forceinline__ float bf16_lo(unsigned pair) { return __builtin_bit_cast(float, pair << 16); }
 __device__ __forceinline__ float bf16_hi(unsigned pair) { return __builtin_bit_cast(float, pair & 0xffff0000u); }
+// element e of a window held as bf16 pairs d[e / 2]
+__device__ __forceinline__ float win_elem(const unsigned *d, int e) { return (e & 1) ? bf16_hi(d[e >> 1]) : bf16_lo(d[e >> 1]); }
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {
     // plain casts: hipcc emits v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
     const u16 l = __builtin_bit_cast(u16, (__bf16) lo);
@@ -68,13 +79,177 @@ struct Args3Dh {
     int tiles_x, tiles_y;
 };
 
+template <int TAPSET, int RY, int CPL>
+__global__ __launch_bounds__(256, (CPL == 4 ? 4 : 3)) void stencil3d_bf16_kernel(const Args3Dh a, const Taps27f W) {
+    using G = Geo<CPL>;
+    constexpr int TY = 4 * RY;
+    constexpr int LH = TY + 2;
+    constexpr int NCHUNK = LH * G::kChunksPerRow;
+    constexpr int NIT = (NCHUNK + 255) / 256;
+    constexpr int ND = G::kWinDwords;
+    __shared__ u32x4 tile[2][NCHUNK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+
+    const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int per_chunk = a.tiles_x * a.tiles_y;
+    const int chunk = lin / per_chunk;
+    const int rem = lin - chunk * per_chunk;
+    const int ty = rem / a.tiles_x;
+    const int tx = rem - ty * a.tiles_x;
+    const int k0 = a.z_begin + chunk * a.zc;
+    const int i0 = ty * TY;
+    const int j0 = tx * G::kTileW;
+    const int zc = min(a.zc, a.z_end - k0);
+    const int nplanes = zc + 2;
+
+    long goff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int k = tid + it * 256;
+        const int r = k / G::kChunksPerRow;
+        const int c = k - r * G::kChunksPerRow;
+        const int gr = min(i0 + 1 + r, a.m + 3);  // padded rows i0+1 .. i0+TY+2
+        const int gc = min(j0 + 8 * c, a.n);      // padded columns j0 .. in 8-element pieces
+        goff[it] = (long) gr * a.ld + gc;
+    }
+    u32x4 stage[NIT];
+    auto load_plane = [&](int p) {
+        const u16 *src = a.in + (long) min(k0 + p, a.h + 1) * a.plane;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (NCHUNK % 256 == 0 || tid + it * 256 < NCHUNK) stage[it] = *reinterpret_cast<const u32x4 *>(src + goff[it]);
+        }
+    };
+    auto write_plane = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int k = tid + it * 256;
+            if (NCHUNK % 256 == 0 || k < NCHUNK) tile[buf][k] = stage[it];
+        }
+    };
+
+    // fp32 accumulators as column PAIRS (v_pk_fma_f32 applies one tap to two adjacent columns per instruction)
+    f2 acc[3][RY][CPL / 2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+#pragma unroll
+            for (int c = 0; c < CPL / 2; ++c) acc[s][r][c] = (f2){0.0f, 0.0f};
+
+    const int col = j0 + CPL * lane;
+    const bool col_ok = col < a.n;
+    // window of a lane: tile columns CPL*lane .. CPL*lane+CPL+7 (own columns start at +4), 8-byte reads
+    const int strip_off = (wv * RY) * G::kLdsW + CPL * lane;
+    u16 *const out_col = a.out + (long) (i0 + wv * RY + 2) * a.ld + (col + 4);
+
+    load_plane(0);
+    write_plane(0);
+    __syncthreads();
+
+    auto consume = [&](int p, auto phase_tag) {
+        constexpr int PHASE = decltype(phase_tag)::value;
+        const bool more = p + 1 < nplanes;
+        if (more) load_plane(p + 1);
+        const u16 *strip = reinterpret_cast<const u16 *>(&tile[p & 1][0]) + strip_off;
+#pragma unroll
+        for (int j = 0; j < RY + 2; ++j) {
+            // d[i] holds window elements (2i, 2i+1).  A tap dx of column pair c needs elements (3+2c+dx, 4+2c+dx):
+            // pairs starting at 3 .. CPL+3, built as register pairs so that packed FMAs read them directly
+            unsigned d[ND];
+#pragma unroll
+            for (int q = 0; q < ND / 2; ++q) {
+                const u32x2 v = *reinterpret_cast<const u32x2 *>(strip + j * G::kLdsW + 4 * q);
+                d[2 * q] = v.x;
+                d[2 * q + 1] = v.y;
+            }
+            f2 pr[CPL + 1];  // pr[k] = elements (3+k, 4+k)
+#pragma unroll
+            for (int k = 0; k < CPL + 1; ++k) pr[k] = (f2){win_elem(d, 3 + k), win_elem(d, 4 + k)};
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                const int s = (PHASE - dz + 3) % 3;
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    const int dy = j - r;
+                    if (dy >= 0 && dy < 3) {
+#pragma unroll
+                        for (int dx = 0; dx < 3; ++dx) {
+                            if (tap_on3<TAPSET>(dz, dy, dx)) {
+                                const float wt = W.w[dz * 9 + dy * 3 + dx];
+                                const f2 wt2 = (f2){wt, wt};
+#pragma unroll
+                                for (int c = 0; c < CPL / 2; ++c)
+                                    acc[s][r][c] = __builtin_elementwise_fma(wt2, pr[2 * c + dx], acc[s][r][c]);
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int r = 0; r < RY; ++r)
+#pragma unroll
+                for (int c = 0; c < CPL / 2; ++c) asm volatile("" : "+v"(acc[s][r][c]));
+
+        {
+            constexpr int s = (PHASE - 2 + 3) % 3;
+            const int o = p - 2;
+            if (o >= 0 && o < zc && col_ok) {
+                u16 *dst = out_col + (long) (k0 + o + 1) * a.plane;
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    if (i0 + wv * RY + r < a.m) {
+#pragma unroll
+                        for (int h = 0; h < CPL / 4; ++h) {  // 8 bytes (4 columns) per store
+                            u32x2 v;
+                            v.x = pack_bf16(acc[s][r][2 * h].x, acc[s][r][2 * h].y);
+                            v.y = pack_bf16(acc[s][r][2 * h + 1].x, acc[s][r][2 * h + 1].y);
+                            *reinterpret_cast<u32x2 *>(dst + (long) r * a.ld + 4 * h) = v;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < RY; ++r)
+#pragma unroll
+                for (int c = 0; c < CPL / 2; ++c) acc[s][r][c] = (f2){0.0f, 0.0f};
+        }
+        if (more) write_plane((p + 1) & 1);
+        __syncthreads();
+    };
+
+    for (int p = 0; p < nplanes; p += 3) {
+        consume(p, std::integral_constant<int, 0>{});
+        if (p + 1 < nplanes) consume(p + 1, std::integral_constant<int, 1>{});
+        if (p + 2 < nplanes) consume(p + 2, std::integral_constant<int, 2>{});
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA ring variant.  The register-staged kernel above keeps ONE plane tile (9.5 KB) per workgroup in flight; with
+// 5 workgroups per CU that is ~47 KB per CU against a loaded HBM latency of ~4 us, i.e. ~4 TB/s -- exactly where it
+// sits (PMC), whatever the FMA count.  Here the planes travel global -> LDS directly (global_load_lds_dwordx4, no
+// staging registers) into a 3-slot ring, TWO planes ahead of the one being consumed.  LDS-DMA completion is only
+// ordered by the issuing wave's vmcnt, so the waits are hand-counted: every iteration issues exactly NIT DMA
+// instructions and RY buffer stores (stores of planes that do not exist go through an empty descriptor and are
+// dropped by the range check), which makes "plane p has landed" the constant s_waitcnt vmcnt(2 RY + NIT); a raw
+// s_barrier (not __syncthreads, which would drain vmcnt(0)) then publishes every wave's part of the plane.
+// ---------------------------------------------------------------------------------------------------------------
 template <int TAPSET, int RY>
-__global__ __launch_bounds__(256, 4) void stencil3d_bf16_kernel(const Args3Dh a, const Taps27f W) {
+__global__ __launch_bounds__(256, 4) void stencil3d_bf16_ring_kernel(const Args3Dh a, const Taps27f W) {
     constexpr int TY = 4 * RY;
     constexpr int LH = TY + 2;
     constexpr int NCHUNK = LH * kChunksPerRow;
     constexpr int NIT = (NCHUNK + 255) / 256;
-    __shared__ u32x4 tile[2][NCHUNK];
+    constexpr int SLOT = NIT * 256;  // DMA writes whole 64-lane pieces: the tail of a slot is slack
+    __shared__ u32x4 ring[3][SLOT];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -95,63 +270,76 @@ __global__ __launch_bounds__(256, 4) void stencil3d_bf16_kernel(const Args3Dh a,
     long goff[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int k = tid + it * 256;
+        const int k = min(tid + it * 256, NCHUNK - 1);  // lanes past the tile re-read its last piece into the slack
         const int r = k / kChunksPerRow;
         const int c = k - r * kChunksPerRow;
-        const int gr = min(i0 + 1 + r, a.m + 3);  // padded rows i0+1 .. i0+TY+2
-        const int gc = min(j0 + 8 * c, a.n);      // padded columns j0 .. j0+263 in 8-element pieces
+        const int gr = min(i0 + 1 + r, a.m + 3);
+        const int gc = min(j0 + 8 * c, a.n);
         goff[it] = (long) gr * a.ld + gc;
     }
-    u32x4 stage[NIT];
-    auto load_plane = [&](int p) {
+    auto issue_plane = [&](int p, int slot) {
         const u16 *src = a.in + (long) min(k0 + p, a.h + 1) * a.plane;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            if (NCHUNK % 256 == 0 || tid + it * 256 < NCHUNK) stage[it] = *reinterpret_cast<const u32x4 *>(src + goff[it]);
-        }
-    };
-    auto write_plane = [&](int buf) {
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int k = tid + it * 256;
-            if (NCHUNK % 256 == 0 || k < NCHUNK) tile[buf][k] = stage[it];
+            // LDS destination = wave-uniform base (M0) + lane * 16: this wave's 64 pieces of iteration `it`
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (src + goff[it]),
+                                             (__attribute__((address_space(3))) void *) &ring[slot][it * 256 + (tid & ~63)],
+                                             16, 0, 0);
         }
     };
 
-    float acc[3][RY][4];
+    f2 acc[3][RY][2];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int r = 0; r < RY; ++r)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[s][r][c] = 0.0f;
+            for (int c = 0; c < 2; ++c) acc[s][r][c] = (f2){0.0f, 0.0f};
 
     const int col = j0 + 4 * lane;
-    const bool col_ok = col < a.n;
-    // window of a lane: tile columns 4*lane .. 4*lane+11 (own columns are 4*lane+4 .. +7), three 8-byte reads
     const int strip_off = (wv * RY) * kLdsW + 4 * lane;
-    u16 *const out_col = a.out + (long) (i0 + wv * RY + 2) * a.ld + (col + 4);
+    unsigned store_off[RY];  // byte offset inside an output plane, or out of range for lanes that must not store
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const int row = i0 + wv * RY + r;
+        store_off[r] = (col < a.n && row < a.m) ? (unsigned) (((long) (row + 2) * a.ld + (col + 4)) * 2) : 0xffffffffu;
+    }
+    const unsigned plane_bytes = (unsigned) (a.plane * 2);
 
-    load_plane(0);
-    write_plane(0);
-    __syncthreads();
+    issue_plane(0, 0);
+    issue_plane(1, 1);
 
     auto consume = [&](int p, auto phase_tag) {
-        constexpr int PHASE = decltype(phase_tag)::value;
-        const bool more = p + 1 < nplanes;
-        if (more) load_plane(p + 1);
-        const u16 *strip = reinterpret_cast<const u16 *>(&tile[p & 1][0]) + strip_off;
+        constexpr int PHASE = decltype(phase_tag)::value;  // = p mod 3 = ring slot of plane p
+        // younger operations than plane p's DMA: NIT (plane p+1) for p = 0; + RY stores for p = 1; 2 RY + NIT in
+        // steady state; 2 RY for the last plane (no plane p+1 was requested)
+        if (p == 0)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT) : "memory");
+        else if (p == 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT + RY) : "memory");
+        else if (p == nplanes - 1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RY) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RY + NIT) : "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (p + 2 < nplanes) issue_plane(p + 2, (PHASE + 2) % 3);  // slot of plane p-1: every wave is done with it
+        const u16 *strip = reinterpret_cast<const u16 *>(&ring[PHASE][0]) + strip_off;
 #pragma unroll
         for (int j = 0; j < RY + 2; ++j) {
-            float win[12];
+            unsigned d[6];
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
                 const u32x2 v = *reinterpret_cast<const u32x2 *>(strip + j * kLdsW + 4 * q);
-                win[4 * q + 0] = bf16_lo(v.x);
-                win[4 * q + 1] = bf16_hi(v.x);
-                win[4 * q + 2] = bf16_lo(v.y);
-                win[4 * q + 3] = bf16_hi(v.y);
+                d[2 * q] = v.x;
+                d[2 * q + 1] = v.y;
             }
+            f2 pr[5];
+            pr[0] = (f2){bf16_hi(d[1]), bf16_lo(d[2])};
+            pr[1] = (f2){bf16_lo(d[2]), bf16_hi(d[2])};
+            pr[2] = (f2){bf16_hi(d[2]), bf16_lo(d[3])};
+            pr[3] = (f2){bf16_lo(d[3]), bf16_hi(d[3])};
+            pr[4] = (f2){bf16_hi(d[3]), bf16_lo(d[4])};
 #pragma unroll
             for (int dz = 0; dz < 3; ++dz) {
                 const int s = (PHASE - dz + 3) % 3;
@@ -163,8 +351,10 @@ __global__ __launch_bounds__(256, 4) void stencil3d_bf16_kernel(const Args3Dh a,
                         for (int dx = 0; dx < 3; ++dx) {
                             if (tap_on3<TAPSET>(dz, dy, dx)) {
                                 const float wt = W.w[dz * 9 + dy * 3 + dx];
+                                const f2 wt2 = (f2){wt, wt};
 #pragma unroll
-                                for (int c = 0; c < 4; ++c) acc[s][r][c] = fmaf(wt, win[3 + c + dx], acc[s][r][c]);
+                                for (int c = 0; c < 2; ++c)
+                                    acc[s][r][c] = __builtin_elementwise_fma(wt2, pr[2 * c + dx], acc[s][r][c]);
                             }
                         }
                     }
@@ -175,31 +365,25 @@ __global__ __launch_bounds__(256, 4) void stencil3d_bf16_kernel(const Args3Dh a,
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
-            for (int r = 0; r < RY; ++r)
-                asm volatile("" : "+v"(acc[s][r][0]), "+v"(acc[s][r][1]), "+v"(acc[s][r][2]), "+v"(acc[s][r][3]));
-
+            for (int r = 0; r < RY; ++r) asm volatile("" : "+v"(acc[s][r][0]), "+v"(acc[s][r][1]));
         {
             constexpr int s = (PHASE - 2 + 3) % 3;
             const int o = p - 2;
-            if (o >= 0 && o < zc && col_ok) {
-                u16 *dst = out_col + (long) (k0 + o + 1) * a.plane;
+            const bool live = o >= 0 && o < zc;
+            const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+                a.out + (long) min(max(k0 + o + 1, 0), a.h) * a.plane, 0, live ? plane_bytes : 0u, 0x00020000);
 #pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    if (i0 + wv * RY + r < a.m) {
-                        u32x2 v;
-                        v.x = pack_bf16(acc[s][r][0], acc[s][r][1]);
-                        v.y = pack_bf16(acc[s][r][2], acc[s][r][3]);
-                        *reinterpret_cast<u32x2 *>(dst + (long) r * a.ld) = v;
-                    }
-                }
+            for (int r = 0; r < RY; ++r) {
+                u32x2 v;
+                v.x = pack_bf16(acc[s][r][0].x, acc[s][r][0].y);
+                v.y = pack_bf16(acc[s][r][1].x, acc[s][r][1].y);
+                __builtin_amdgcn_raw_buffer_store_b64(v, dst, store_off[r], 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < RY; ++r)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[s][r][c] = 0.0f;
+                for (int c = 0; c < 2; ++c) acc[s][r][c] = (f2){0.0f, 0.0f};
         }
-        if (more) write_plane((p + 1) & 1);
-        __syncthreads();
     };
 
     for (int p = 0; p < nplanes; p += 3) {
@@ -209,9 +393,10 @@ __global__ __launch_bounds__(256, 4) void stencil3d_bf16_kernel(const Args3Dh a,
     }
 }
 
-template <int TAPSET>
+template <int TAPSET, int CPL>
 hipError_t launch_bf16(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s) {
     constexpr int RY = 4, TY = 4 * RY;
+    constexpr int kTileW = Geo<CPL>::kTileW;
     Args3Dh a;
     a.in = static_cast<const u16 *>(in);
     a.out = static_cast<u16 *>(out);
@@ -231,15 +416,21 @@ hipError_t launch_bf16(const Plan &p, const void *in, void *out, int begin, int 
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
     Taps27f w;
     for (int k = 0; k < 27; ++k) w.w[k] = (float) p.w[k];
-    hipLaunchKernelGGL((stencil3d_bf16_kernel<TAPSET, RY>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
+    if (a.plane * 2 >= (1L << 32)) return hipErrorInvalidValue;  // per-plane buffer descriptors: 32-bit offsets
+    if (CPL == 4 && p.lds_dma)
+        hipLaunchKernelGGL((stencil3d_bf16_ring_kernel<TAPSET, RY>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
+    else
+        hipLaunchKernelGGL((stencil3d_bf16_kernel<TAPSET, RY, CPL>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
     return hipGetLastError();
 }
 
 }  // namespace
 
 hipError_t launch_3d_bf16(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s) {
-    if (p.tapset == TAPS3D_STAR) return launch_bf16<TAPS3D_STAR>(p, in, out, begin, end, s);
-    return launch_bf16<TAPS3D_BOX>(p, in, out, begin, end, s);
+    const bool wide = p.cols_per_lane == 8 && !p.lds_dma;
+    if (p.tapset == TAPS3D_STAR)
+        return wide ? launch_bf16<TAPS3D_STAR, 8>(p, in, out, begin, end, s) : launch_bf16<TAPS3D_STAR, 4>(p, in, out, begin, end, s);
+    return wide ? launch_bf16<TAPS3D_BOX, 8>(p, in, out, begin, end, s) : launch_bf16<TAPS3D_BOX, 4>(p, in, out, begin, end, s);
 }
 
 const char *kernel_name_3d_bf16(const Plan &) { return "stencil3d_bf16_kernel"; }

@@ -350,6 +350,12 @@ def test_bf16_sweeps_match_oracle_bit_exact(L, O, shape, dims):
     assert np.isfinite(O.from_bf16(exp)).all()
     for zc in (1, 4, 16):
         assert np.array_equal(plan_run_bf16(L, shape, bits, 12, weights=w, options={"z_chunk": zc}), exp)
+        # LDS-DMA ring variant (global_load_lds, two planes ahead, hand-counted vmcnt)
+        assert np.array_equal(plan_run_bf16(L, shape, bits, 12, weights=w, options={"z_chunk": zc, "lds_dma": 1}), exp)
+    for t in (1, 3):
+        assert np.array_equal(plan_run_bf16(L, shape, bits, t, options={"lds_dma": 1}), O.run_bf16(shape, bits, t))
+        # 8 columns per lane (1 KiB row pieces per wave)
+        assert np.array_equal(plan_run_bf16(L, shape, bits, t, options={"cols_per_lane": 8}), O.run_bf16(shape, bits, t))
 
 
 def test_bf16_host_operator_and_random_taps(L, O):
