@@ -116,12 +116,26 @@ def main():
     import torch
     import torch.distributed as dist
 
-    import lorastencil_amd as L
-    from lorastencil_amd import slab
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # the engine normally arrives prebuilt with the snapshot; if it did not, local rank 0 builds it (hipcc), the
+    # other ranks wait for the library to appear -- there is no other implementation to fall back to
+    lib_path = os.path.join(ROOT, "lorastencil_amd", "lib", "liblorastencil_hip.so")
+    if not os.path.exists(lib_path):
+        if local_rank == 0:
+            import __graft_entry__ as g
+
+            g.build(only_if_missing=True)
+        else:
+            t_wait = time.time()
+            while not os.path.exists(lib_path) and time.time() - t_wait < 900:
+                time.sleep(2)
+            time.sleep(5)  # let the linker finish writing
+
+    import lorastencil_amd as L
+    from lorastencil_amd import slab
+
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")

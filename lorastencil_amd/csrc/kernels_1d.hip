@@ -9,13 +9,11 @@
 // order (the order of the reference's CPU check, 1d/main.cu:34-40) with fused multiply-adds and writes 16 bytes.
 #include <hip/hip_runtime.h>
 
-#include "engine.h"
+#include "device_common.h"
 
 namespace lora {
 
 namespace {
-
-typedef double d2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void stencil1d_kernel(const double *__restrict__ in, double *__restrict__ out,
                                                         int begin, int end, const Taps9 W) {

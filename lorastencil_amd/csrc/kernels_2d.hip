@@ -24,49 +24,15 @@
 //     any even n work; the reference has no guards.
 #include <hip/hip_runtime.h>
 
-#include "engine.h"
+#include "device_common.h"
 
 namespace lora {
 
 namespace {
 
-typedef double d2 __attribute__((ext_vector_type(2)));
-
 constexpr int kTileW = 128;            // output columns per tile: 64 lanes x 2
 constexpr int kLdsW = kTileW + 8;      // staged columns (halo 3 each side, widened to 4 for alignment)
 constexpr int kChunksPerRow = kLdsW / 2;  // 16-byte chunks per staged row
-
-template <int TAPSET>
-__host__ __device__ constexpr bool tap_on(int dy, int dx) {
-    const int ay = dy < 3 ? 3 - dy : dy - 3;
-    const int ax = dx < 3 ? 3 - dx : dx - 3;
-    return TAPSET == TAPS2D_BOX ? true : (TAPSET == TAPS2D_STAR ? (ay == 0 || ax == 0) : (ay + ax <= 3));
-}
-
-// Blocks that share an XCD (equal b % 8) get a contiguous run of the linear tile order.
-__device__ __forceinline__ int xcd_contiguous(int b, int nb) {
-    const int q = nb >> 3, r = nb & 7;
-    const int xcd = b & 7, slot = b >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + slot;
-}
-
-// Linear index -> tile coordinates, panel-major: panels of `pw` tile columns, each walked row by row.
-__device__ __forceinline__ void panel_major(int lin, int tiles_x, int tiles_y, int pw, int &ty, int &tx) {
-    const int per_panel = pw * tiles_y;
-    const int full = tiles_x / pw;
-    const int p = lin / per_panel;
-    if (p < full) {
-        const int q = lin - p * per_panel;
-        ty = q / pw;
-        tx = p * pw + (q - ty * pw);
-    } else {
-        const int rem = tiles_x - full * pw;
-        const int q = lin - full * per_panel;
-        ty = q / rem;
-        tx = full * pw + (q - ty * rem);
-    }
-}
 
 struct Args2D {
     const double *in;

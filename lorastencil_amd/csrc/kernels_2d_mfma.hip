@@ -23,14 +23,11 @@
 
 #include <cstring>
 
-#include "engine.h"
+#include "device_common.h"
 
 namespace lora {
 
 namespace {
-
-typedef double d2 __attribute__((ext_vector_type(2)));
-typedef double d4 __attribute__((ext_vector_type(4)));
 
 constexpr int kTH = 32;                  // output rows per workgroup
 constexpr int kTW = 128;                 // output columns per workgroup
@@ -39,29 +36,6 @@ constexpr int kLW = kTW + 16;            // staged columns: T block 4 of the rig
 constexpr int kChunks = kLW / 2;         // 16-byte chunks per staged row
 constexpr int kNChunk = kLH * kChunks;   // 2880
 constexpr int kNIT = (kNChunk + 255) / 256;
-
-__device__ __forceinline__ int xcd_contiguous(int b, int nb) {
-    const int q = nb >> 3, r = nb & 7;
-    const int xcd = b & 7, slot = b >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + slot;
-}
-
-__device__ __forceinline__ void panel_major(int lin, int tiles_x, int tiles_y, int pw, int &ty, int &tx) {
-    const int per_panel = pw * tiles_y;
-    const int full = tiles_x / pw;
-    const int p = lin / per_panel;
-    if (p < full) {
-        const int q = lin - p * per_panel;
-        ty = q / pw;
-        tx = p * pw + (q - ty * pw);
-    } else {
-        const int rem = tiles_x - full * pw;
-        const int q = lin - full * per_panel;
-        ty = q / rem;
-        tx = full * pw + (q - ty * rem);
-    }
-}
 
 struct ArgsMfma {
     const double *in;

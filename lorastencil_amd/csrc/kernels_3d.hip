@@ -20,13 +20,12 @@
 //   * blocks that share an XCD get a contiguous run of tiles so that x/y halos are re-read from that XCD's L2.
 #include <hip/hip_runtime.h>
 
-#include "engine.h"
+#include "device_common.h"
 
 namespace lora {
 
 namespace {
 
-typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int kTileW = 128;
 constexpr int kLdsW = kTileW + 8;
@@ -35,13 +34,6 @@ constexpr int kChunksPerRow = kLdsW / 2;
 template <int TAPSET>
 __host__ __device__ constexpr bool tap_on3(int dz, int dy, int dx) {
     return TAPSET == TAPS3D_BOX ? true : (((dz != 1) + (dy != 1) + (dx != 1)) <= 1);
-}
-
-__device__ __forceinline__ int xcd_contiguous(int b, int nb) {
-    const int q = nb >> 3, r = nb & 7;
-    const int xcd = b & 7, slot = b >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + slot;
 }
 
 struct Args3D {

@@ -18,7 +18,7 @@
 // The innermost extent must be a multiple of 8 (16-byte row pieces).
 #include <hip/hip_runtime.h>
 
-#include "engine.h"
+#include "device_common.h"
 
 namespace lora {
 
@@ -48,13 +48,6 @@ struct Taps27f {
 template <int TAPSET>
 __host__ __device__ constexpr bool tap_on3(int dz, int dy, int dx) {
     return TAPSET == TAPS3D_BOX ? true : (((dz != 1) + (dy != 1) + (dx != 1)) <= 1);
-}
-
-__device__ __forceinline__ int xcd_contiguous(int b, int nb) {
-    const int q = nb >> 3, r = nb & 7;
-    const int xcd = b & 7, slot = b >> 3;
-    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return start + slot;
 }
 
 __device__ __forceinline__ float bf16_lo(unsigned pair) { return __builtin_bit_cast(float, pair << 16); }
