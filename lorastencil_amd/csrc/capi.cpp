@@ -123,6 +123,7 @@ static void derive_lowrank(Plan &p) {
 }
 
 void plan_refresh(Plan &p) {
+    ++p.epoch;
     if (p.ndim == 2) {
         // smallest tap set that covers the non-zero pattern of the applied taps
         bool diamond = true, star = true;
@@ -293,7 +294,10 @@ int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, con
     return LORA_OK;
 }
 
-void lora_plan_destroy(lora_plan *plan) { delete plan; }
+void lora_plan_destroy(lora_plan *plan) {
+    if (plan && plan->graph_exec) (void) hipGraphExecDestroy(plan->graph_exec);
+    delete plan;
+}
 
 int lora_plan_set_weights(lora_plan *plan, const double *weights, int count) {
     if (!plan || !weights || count != plan->p.ntaps) return LORA_EINVAL;
@@ -338,6 +342,9 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         p.nt_store = value ? 1 : 0;
     } else if (!std::strcmp(key, "persistent")) {
         p.persistent = value ? 1 : 0;
+    } else if (!std::strcmp(key, "graph")) {
+        if (value < -1 || value > 1) return LORA_EINVAL;
+        p.use_graph = value;
     } else if (!std::strcmp(key, "lds_dma")) {
         p.lds_dma = value ? 1 : 0;
     } else if (!std::strcmp(key, "cols_per_lane")) {
@@ -371,6 +378,8 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.nt_store;
     else if (!std::strcmp(key, "persistent"))
         *value = p.persistent;
+    else if (!std::strcmp(key, "graph"))
+        *value = p.use_graph;
     else if (!std::strcmp(key, "lds_dma"))
         *value = p.lds_dma;
     else if (!std::strcmp(key, "cols_per_lane"))
@@ -427,8 +436,8 @@ int lora_plan_step2(lora_plan *plan, const void *d_in, void *d_out, void *stream
     return lora_plan_step2_region(plan, d_in, d_out, 0, plan->p.dims[0], stream);
 }
 
-int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream) {
-    if (!plan || times < 0) return LORA_EINVAL;
+// The launches of one run, in order, on `stream` (also what gets captured into a hipGraph).
+static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream) {
     Plan &p = plan->p;
     void *buf[2] = {d_buf0, d_buf1};
     int done = 0;
@@ -459,6 +468,70 @@ int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *
     for (int i = done; i < times; ++i) {  // 2d/gpu.cu:544-546
         const int rc = lora_plan_step(plan, buf[i % 2], buf[(i + 1) % 2], stream);
         if (rc != LORA_OK) return rc;
+    }
+    return LORA_OK;
+}
+
+static void drop_graph(lora_plan *plan) {
+    if (plan->graph_exec) {
+        (void) hipGraphExecDestroy(plan->graph_exec);
+        plan->graph_exec = nullptr;
+    }
+    plan->graph_times = -1;
+}
+
+int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream) {
+    if (!plan || times < 0) return LORA_EINVAL;
+    Plan &p = plan->p;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    // Launch-bound runs (small grids, many steps: the reference's 1D size sweeps in ~2 us per step) are captured
+    // once into a hipGraph and replayed; big grids gain nothing and are launched directly.  Capture needs a real
+    // stream (not the legacy default one), no capture already in progress, and kernels that do no host-side work
+    // at launch (the MFMA variant uploads its band tables).
+    bool want = p.use_graph == 1 || (p.use_graph < 0 && times >= 16 && lora_plan_padded_bytes(plan) <= (64u << 20));
+    if (want && (s == nullptr || p.variant == LORA_VARIANT_MFMA)) want = false;
+    if (want) {
+        hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {
+            (void) hipGetLastError();
+            want = false;
+        }
+    }
+    if (!want) return run_launches(plan, d_buf0, d_buf1, times, stream);
+
+    if (!(plan->graph_exec && plan->graph_buf[0] == d_buf0 && plan->graph_buf[1] == d_buf1 &&
+          plan->graph_times == times && plan->graph_epoch == p.epoch)) {
+        drop_graph(plan);
+        if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
+        hipGraph_t graph = nullptr;
+        hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            return run_launches(plan, d_buf0, d_buf1, times, stream);
+        }
+        const int rc = run_launches(plan, d_buf0, d_buf1, times, stream);
+        e = hipStreamEndCapture(s, &graph);
+        if (rc != LORA_OK || e != hipSuccess || !graph) {
+            if (graph) (void) hipGraphDestroy(graph);
+            (void) hipGetLastError();
+            return rc != LORA_OK ? rc : run_launches(plan, d_buf0, d_buf1, times, stream);
+        }
+        e = hipGraphInstantiate(&plan->graph_exec, graph, nullptr, nullptr, 0);
+        (void) hipGraphDestroy(graph);
+        if (e != hipSuccess) {
+            plan->graph_exec = nullptr;
+            (void) hipGetLastError();
+            return run_launches(plan, d_buf0, d_buf1, times, stream);
+        }
+        plan->graph_buf[0] = d_buf0;
+        plan->graph_buf[1] = d_buf1;
+        plan->graph_times = times;
+        plan->graph_epoch = p.epoch;
+    }
+    const hipError_t e = hipGraphLaunch(plan->graph_exec, s);
+    if (e != hipSuccess) {
+        lora::set_last_error("hipGraphLaunch", e);
+        return LORA_EHIP;
     }
     return LORA_OK;
 }
@@ -532,12 +605,29 @@ int lora_run_host_dtype(int shape, int dtype, const void *in, void *out, const d
         if (rc != LORA_OK) return rc;
     }
     LORA_HIP_TRY(hipMemset(dev.b[1], 0, bytes));
+    // a stream of our own: launch-bound runs are replayed from a hipGraph, which the legacy default stream cannot capture
+    struct StreamGuard {
+        hipStream_t s = nullptr;
+        ~StreamGuard() {
+            if (s) (void) hipStreamDestroy(s);
+        }
+    } sg;
+    LORA_HIP_TRY(hipStreamCreateWithFlags(&sg.s, hipStreamNonBlocking));
+    LORA_HIP_TRY(hipDeviceSynchronize());
+    if (times >= 16 && bytes <= (64u << 20)) {
+        // build (capture + instantiate) the graph outside the timed region, like the reference's setup work
+        rc = lora_plan_run(plan, dev.b[0], dev.b[1], times, sg.s);
+        if (rc != LORA_OK) return rc;
+        LORA_HIP_TRY(hipStreamSynchronize(sg.s));
+        LORA_HIP_TRY(hipMemcpy(dev.b[0], in, bytes, hipMemcpyHostToDevice));
+        LORA_HIP_TRY(hipMemset(dev.b[1], 0, bytes));
+    }
     LORA_HIP_TRY(hipDeviceSynchronize());
 
     const auto t0 = clock::now();
-    rc = lora_plan_run(plan, dev.b[0], dev.b[1], times, nullptr);
+    rc = lora_plan_run(plan, dev.b[0], dev.b[1], times, sg.s);
     if (rc != LORA_OK) return rc;
-    LORA_HIP_TRY(hipDeviceSynchronize());
+    LORA_HIP_TRY(hipStreamSynchronize(sg.s));
     const auto t1 = clock::now();
 
     // 1D copies all but the last element (1d/gpu_1r.cu:134)

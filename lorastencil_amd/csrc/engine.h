@@ -65,6 +65,8 @@ struct Plan {
     bool lowrank_valid = false;
     LowRank2D lowrank{};
     std::string kernel_name;
+    int use_graph = -1;   // -1 auto (small grids, many launches, non-default stream), 0 never, 1 whenever possible
+    unsigned epoch = 0;   // bumped by every change of taps / options: invalidates a cached graph
 };
 
 void plan_refresh(Plan &p);  // re-derive tapset / low-rank factors / kernel name from w + options
@@ -99,4 +101,9 @@ void set_last_error(const char *what, hipError_t e);
 
 struct lora_plan {
     lora::Plan p;
+    // hipGraph of the last lora_plan_run (launch-bound small grids): replayed while buffers / step count match
+    hipGraphExec_t graph_exec = nullptr;
+    void *graph_buf[2] = {nullptr, nullptr};
+    int graph_times = -1;
+    unsigned graph_epoch = 0;  // value of p.epoch the graph was captured at
 };

@@ -393,6 +393,48 @@ def test_params_are_honoured_like_the_reference(L, O):
     assert np.array_equal(plan_run(L, "box2d3r", a, 2, params=p), O.run("box2d3r", a, 2, params=p))
 
 
+@pytest.mark.parametrize("shape,dims,t", [("1d1r", (1 << 16,), 40), ("star2d1r", (128, 256), 21), ("star3d1r", (8, 16, 64), 17)])
+def test_graph_replay_of_launch_bound_runs(L, O, shape, dims, t):
+    """lora_plan_run captures small, many-step runs into a hipGraph (needs a non-default stream) and replays it."""
+    import torch
+
+    a = O.reference_input(shape, dims)
+    w = O.effective_weights(shape)
+    w = w / w.sum()
+    exp = O.run(shape, a, t, weights=w)
+    plan = L.Plan(shape, dims).set_weights(w)
+    plan.set_option("graph", 1)
+    stream = torch.cuda.Stream()
+    for rep in range(3):  # capture once, then two replays of the cached graph
+        b0 = torch.from_numpy(a).cuda()
+        b1 = torch.zeros_like(b0)
+        if rep:
+            keep0.copy_(b0)
+            keep1.zero_()
+            b0, b1 = keep0, keep1
+        else:
+            keep0, keep1 = b0, b1
+        torch.cuda.synchronize()
+        plan.run(b0, b1, t, stream=stream)
+        stream.synchronize()
+        got = (b0, b1)[t % 2].cpu().numpy()
+        if a.ndim == 1:
+            got[-1] = exp[-1]
+        assert rel_err(got, exp) < 1e-13, rep
+    # new taps invalidate the cached graph
+    plan.set_weights(w * 0.5)
+    keep0.copy_(torch.from_numpy(a))
+    keep1.zero_()
+    torch.cuda.synchronize()
+    plan.run(keep0, keep1, t, stream=stream)
+    stream.synchronize()
+    got = (keep0, keep1)[t % 2].cpu().numpy()
+    exp2 = O.run(shape, a, t, weights=w * 0.5)
+    if a.ndim == 1:
+        got[-1] = exp2[-1]
+    assert rel_err(got, exp2) < 1e-13
+
+
 def test_halo_cells_are_never_written(L, O):
     import torch
 
