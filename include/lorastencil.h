@@ -190,6 +190,12 @@ int lora_effective_weights(int shape, const double *params, double *weights);
  * reference silently drops. */
 int lora_factorize_7x7(const double *params, double *u, double *v, double *residual_max);
 
+/* Rank-revealing factorisation of ANY 7x7 tap matrix (one-sided Jacobi SVD):
+ * weights = sum_k u[k] (x) v[k], u[k] = sigma_k a_k (vertical profile), v[k] = b_k (horizontal profile), k = 0..6 in
+ * order of decreasing singular value sigma[k] (7x7, 7x7 and 7 doubles).  Keeping `r` terms leaves a residual of
+ * spectral norm sigma[r].  The MFMA variant uses it for taps the pyramid factoriser cannot take. */
+int lora_svd_7x7(const double *weights, double *u, double *v, double *sigma);
+
 /* bf16 <-> double on the host (round-to-nearest-even; bf16 values are bit patterns in uint16_t). */
 void lora_f64_to_bf16(const double *src, uint16_t *dst, size_t count);
 void lora_bf16_to_f64(const uint16_t *src, double *dst, size_t count);

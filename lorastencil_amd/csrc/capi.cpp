@@ -109,17 +109,39 @@ static void derive_lowrank(Plan &p) {
         p.lowrank_valid = finish_residual(1e-14);
         return;
     }
-    // (3) pyramid factorisation
-    double u[4][7], v[4][7];
-    factorize_7x7(W, u, v, nullptr);
-    lr.rank = 3;
-    for (int t = 0; t < 3; ++t)
-        for (int e = 0; e < 7; ++e) {
-            if (!std::isfinite(u[t][e]) || !std::isfinite(v[t][e])) return;
-            lr.u[t][e] = u[t][e];
-            lr.v[t][e] = v[t][e];
+    // (3) pyramid factorisation (the reference's scheme: exact for its symmetric tables)
+    {
+        double u[4][7], v[4][7];
+        factorize_7x7(W, u, v, nullptr);
+        lr.rank = 3;
+        bool finite = true;
+        for (int t = 0; t < 3; ++t)
+            for (int e = 0; e < 7; ++e) {
+                finite = finite && std::isfinite(u[t][e]) && std::isfinite(v[t][e]);
+                lr.u[t][e] = u[t][e];
+                lr.v[t][e] = v[t][e];
+            }
+        if (finite && finish_residual(1e-13)) {
+            p.lowrank_valid = true;
+            return;
         }
-    p.lowrank_valid = finish_residual(1e-13);
+    }
+    // (4) any other taps: truncated SVD, as many terms (<= 3) as the singular values ask for; what three terms do not
+    //     capture must be a few isolated taps (applied on the vector pipe) or the taps are refused for this variant
+    {
+        double u[7][7], v[7][7], sigma[7];
+        lr = LowRank2D{};
+        if (svd_7x7(W, u, v, sigma) != LORA_OK || !(sigma[0] > 0.0)) return;
+        int rank = 1;
+        while (rank < 3 && sigma[rank] > 1e-14 * sigma[0]) ++rank;
+        lr.rank = rank;
+        for (int t = 0; t < rank; ++t)
+            for (int e = 0; e < 7; ++e) {
+                lr.u[t][e] = u[t][e];
+                lr.v[t][e] = v[t][e];
+            }
+        p.lowrank_valid = finish_residual(1e-13);
+    }
 }
 
 void plan_refresh(Plan &p) {

@@ -16,6 +16,7 @@ int shape_ntaps(int shape);
 int default_params(int shape, double *params);
 int effective_weights(int shape, const double *params, double *weights);
 int factorize_7x7(const double *params, double u[4][7], double v[4][7], double *residual_max);
+int svd_7x7(const double *W, double u[7][7], double v[7][7], double sigma[7]);
 
 // ---- tap sets: which of the 49 / 27 taps a kernel instantiation evaluates --------------------
 enum TapSet2D { TAPS2D_DIAMOND = 0, TAPS2D_STAR = 1, TAPS2D_BOX = 2 };

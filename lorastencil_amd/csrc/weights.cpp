@@ -179,6 +179,68 @@ int factorize_7x7(const double *params, double u[4][7], double v[4][7], double *
     return LORA_OK;
 }
 
+// ---- rank-revealing factorisation of an arbitrary 7x7 tap matrix ---------------------------
+// One-sided Jacobi SVD, W = sum_k sigma_k a_k b_k^T with sigma_1 >= sigma_2 >= ...  The pyramid factoriser above
+// only handles symmetric tables whose residuals vanish ring by ring; this one takes any W and tells how many terms it
+// really needs: truncating after `rank` terms leaves a residual of spectral norm sigma_{rank+1} (Eckart-Young), so
+// max|residual entry| <= sigma_{rank+1}.  Terms are returned as u_k = sigma_k a_k (vertical profile), v_k = b_k
+// (horizontal profile); sigma[0..6] holds all singular values.
+int svd_7x7(const double *W, double u[7][7], double v[7][7], double sigma[7]) {
+    // work on G = W (rows i, columns j); rotate column pairs of G until they are mutually orthogonal: G = A S, V acc.
+    double g[7][7], vv[7][7];
+    for (int i = 0; i < 7; ++i)
+        for (int j = 0; j < 7; ++j) {
+            g[i][j] = W[i * 7 + j];
+            vv[i][j] = (i == j) ? 1.0 : 0.0;
+            if (!std::isfinite(g[i][j])) return LORA_EINVAL;
+        }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0.0;
+        for (int p = 0; p < 6; ++p)
+            for (int q = p + 1; q < 7; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 7; ++i) {
+                    alpha += g[i][p] * g[i][p];
+                    beta += g[i][q] * g[i][q];
+                    gamma += g[i][p] * g[i][q];
+                }
+                if (gamma == 0.0) continue;
+                off = std::fmax(off, std::fabs(gamma) / std::sqrt(alpha * beta + 1e-300));
+                const double zeta = (beta - alpha) / (2.0 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (std::fabs(zeta) + std::sqrt(1.0 + zeta * zeta));
+                const double c = 1.0 / std::sqrt(1.0 + t * t), sn = c * t;
+                for (int i = 0; i < 7; ++i) {
+                    const double gp = g[i][p], gq = g[i][q];
+                    g[i][p] = c * gp - sn * gq;
+                    g[i][q] = sn * gp + c * gq;
+                    const double vp = vv[i][p], vq = vv[i][q];
+                    vv[i][p] = c * vp - sn * vq;
+                    vv[i][q] = sn * vp + c * vq;
+                }
+            }
+        if (off < 1e-15) break;
+    }
+    // column norms are the singular values; sort descending
+    int order[7];
+    double nrm[7];
+    for (int j = 0; j < 7; ++j) {
+        double s2 = 0;
+        for (int i = 0; i < 7; ++i) s2 += g[i][j] * g[i][j];
+        nrm[j] = std::sqrt(s2);
+        order[j] = j;
+    }
+    std::sort(order, order + 7, [&](int x, int y) { return nrm[x] > nrm[y]; });
+    for (int k = 0; k < 7; ++k) {
+        const int j = order[k];
+        sigma[k] = nrm[j];
+        for (int i = 0; i < 7; ++i) {
+            u[k][i] = g[i][j];   // = sigma_k a_k
+            v[k][i] = vv[i][j];  // = b_k
+        }
+    }
+    return LORA_OK;
+}
+
 int effective_weights(int shape, const double *params, double *w) {
     switch (shape) {
         case LORA_1D1R:
@@ -291,6 +353,11 @@ int lora_effective_weights(int shape, const double *params, double *weights) {
         params = tmp;
     }
     return lora::effective_weights(shape, params, weights);
+}
+
+int lora_svd_7x7(const double *weights, double *u, double *v, double *sigma) {
+    if (!weights || !u || !v || !sigma) return LORA_EINVAL;
+    return lora::svd_7x7(weights, reinterpret_cast<double(*)[7]>(u), reinterpret_cast<double(*)[7]>(v), sigma);
 }
 
 int lora_factorize_7x7(const double *params, double *u, double *v, double *residual_max) {

@@ -115,6 +115,19 @@ def factorize_7x7(params):
     return u, v, res.value
 
 
+def svd_7x7(weights):
+    """Rank-revealing factorisation of any 7x7 tap matrix: returns (u[7,7], v[7,7], sigma[7]) with
+    weights = sum_k outer(u[k], v[k]) and sigma descending; truncating after r terms leaves spectral error sigma[r]."""
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    if weights.size != 49:
+        raise ValueError("weights must hold 49 values")
+    u = np.zeros((7, 7))
+    v = np.zeros((7, 7))
+    sig = np.zeros(7)
+    check(_lib.lib().lora_svd_7x7(_p(weights), _p(u), _p(v), _p(sig)), "lora_svd_7x7")
+    return u, v, sig
+
+
 class GlibcRand:
     """glibc ``rand()`` stream; seed 1 is what the reference's un-seeded harness draws from."""
 

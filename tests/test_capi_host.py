@@ -78,6 +78,31 @@ def test_factorizer_matches_oracle_and_reports_residual(L):
     assert np.array_equal(w.ravel(), L.effective_weights("box2d3r", p2))
 
 
+def test_svd_factorisation_reveals_rank_and_bounds_the_error(L):
+    rng = np.random.default_rng(21)
+    # exactly rank 2, not symmetric: the pyramid scheme cannot take it, the SVD needs two terms
+    w = np.outer(rng.standard_normal(7), rng.standard_normal(7)) + np.outer(rng.standard_normal(7), rng.standard_normal(7))
+    u, v, sig = L.svd_7x7(w)
+    assert np.all(np.diff(sig) <= 1e-12) and sig[2] < 1e-12 * sig[0]
+    assert np.abs(sum(np.outer(u[k], v[k]) for k in range(2)) - w).max() < 1e-13 * np.abs(w).max()
+    # full-rank random taps: every truncation obeys Eckart-Young and agrees with numpy's singular values
+    w = rng.standard_normal((7, 7))
+    u, v, sig = L.svd_7x7(w)
+    assert np.allclose(sig, np.linalg.svd(w, compute_uv=False), rtol=1e-12, atol=1e-13)
+    for r in range(1, 8):
+        resid = w - sum(np.outer(u[k], v[k]) for k in range(r))
+        bound = sig[r] if r < 7 else 0.0
+        assert np.linalg.norm(resid, 2) <= bound * (1 + 1e-9) + 1e-12
+    # the reference's box table really is rank 3, its star2d1r table rank 4
+    assert (L.svd_7x7(L.default_params("box2d3r"))[2] > 1e-9).sum() == 3
+    assert (L.svd_7x7(L.default_params("star2d1r"))[2] > 1e-9).sum() == 4
+    p = L.Plan("box2d3r", (64, 128))
+    p.set_weights(np.outer([1, 2, 3, 4, 5, 6, 7], [1, -1, 2, -2, 3, -3, 4.0]))  # rank 1, asymmetric
+    p.set_variant(L.VARIANT_MFMA)  # accepted through the SVD path
+    p.set_weights(rng.standard_normal(49))  # rank 7: no low-rank form, the plan falls back to the direct variant
+    assert p.get_option("variant") == L.VARIANT_DIRECT
+
+
 def test_glibc_rand_fill_matches_oracle_and_golden(L):
     r = L.GlibcRand()
     ro = O.Rng()

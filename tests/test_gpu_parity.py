@@ -190,6 +190,12 @@ def test_mfma_variant_real_weights_and_scaling(L, O):
     p[24] = 10.0
     got = plan_run_variant(L, "box2d3r", a, 2, L.VARIANT_MFMA, weights=p / p.sum())
     assert rel_err(got, O.run("box2d3r", a, 2, weights=p / p.sum())) < 1e-13
+    # asymmetric rank-2 taps (plus one isolated tap): outside the pyramid scheme, taken through the SVD factoriser
+    w2 = np.outer(rng.standard_normal(7), rng.standard_normal(7)) + np.outer(rng.standard_normal(7), rng.standard_normal(7))
+    w2[0, 6] += 0.75
+    w2 = (w2 / np.abs(w2).sum()).ravel()
+    got = plan_run_variant(L, "box2d3r", a, 3, L.VARIANT_MFMA, weights=w2)
+    assert rel_err(got, O.run("box2d3r", a, 3, weights=w2)) < 1e-12
     # taps with no low-rank form are refused, not mis-computed
     plan = L.Plan("box2d3r", (64, 256))
     plan.set_weights(rng.standard_normal(49))
