@@ -64,6 +64,16 @@ typedef enum lora_variant {
     LORA_VARIANT_MFMA = 2    /* low-rank (U X) V products on v_mfma_f64_16x16x4 (2D shapes only)   */
 } lora_variant;
 
+/* What the halo cells hold between sweeps of the time-step driver (lora_plan_run and the host operators).
+ * Only LORA_BC_REFERENCE is behaviour of the reference; the other two are SURVEY section 8f-3 options. */
+typedef enum lora_boundary {
+    LORA_BC_REFERENCE = 0, /* halo cells are never written: sweep i reads the halo of buffer i % 2 -- the caller's
+                              values at even steps, the second buffer's (zeros) at odd ones            */
+    LORA_BC_DIRICHLET = 1, /* halo cells keep the caller's input values at every time level                        */
+    LORA_BC_PERIODIC = 2   /* the grid is a torus: before every sweep each halo cell is refreshed from the interior
+                              cell it is a periodic image of (every extent must be >= its halo width)              */
+} lora_boundary;
+
 /* Number of taps in `params` / weights for a shape: 9 (1D), 49 (2D), 27 (3D). */
 int lora_shape_ntaps(int shape);
 /* Number of interior dimensions of a shape (1, 2 or 3), 0 for an unknown shape. */
@@ -149,6 +159,11 @@ int lora_plan_create(lora_plan **plan, int shape, int dtype, const int *dims, co
 int lora_plan_set_weights(lora_plan *plan, const double *weights, int count);
 int lora_plan_get_weights(const lora_plan *plan, double *weights, int count);
 int lora_plan_set_variant(lora_plan *plan, int variant);
+/* Boundary condition applied by lora_plan_run (lora_boundary; lora_plan_step* stay raw sweeps). */
+int lora_plan_set_boundary(lora_plan *plan, int boundary);
+/* Boundary condition given to plans created afterwards on this thread, i.e. also to the host operators of group A
+ * (what the CLIs' --bc flag sets).  Returns the previous value. */
+int lora_set_default_boundary(int boundary);
 /* Integer tuning knob for benchmarking ("rows_per_thread", "panel_width", "steps_per_launch"). */
 int lora_plan_set_option(lora_plan *plan, const char *key, int value);
 int lora_plan_get_option(const lora_plan *plan, const char *key, int *value);

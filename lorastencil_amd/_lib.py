@@ -23,6 +23,7 @@ LORA_ENODEVICE = -5
 F64 = 0
 BF16 = 1
 VARIANT_AUTO, VARIANT_DIRECT, VARIANT_MFMA = 0, 1, 2
+BC_REFERENCE, BC_DIRICHLET, BC_PERIODIC = 0, 1, 2
 
 _dp = ctypes.POINTER(ctypes.c_double)
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -80,6 +81,8 @@ SIGNATURES = {
     "lora_plan_set_weights": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),
     "lora_plan_get_weights": (ctypes.c_int, [_vp, _dp, ctypes.c_int]),
     "lora_plan_set_variant": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lora_plan_set_boundary": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lora_set_default_boundary": (ctypes.c_int, [ctypes.c_int]),
     "lora_plan_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
     "lora_plan_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _ip]),
     "lora_plan_padded_bytes": (ctypes.c_size_t, [_vp]),

@@ -22,6 +22,7 @@
 namespace lora {
 
 static thread_local std::string g_last_error;
+static thread_local int g_default_boundary = LORA_BC_REFERENCE;
 static thread_local lora_run_info g_last_info = {};
 
 void set_last_error(const char *what, hipError_t e) {
@@ -230,6 +231,7 @@ static int step_region(Plan &p, const void *d_in, void *d_out, int begin, int en
 
 }  // namespace lora
 
+using lora::g_default_boundary;
 using lora::g_last_error;
 using lora::Plan;
 
@@ -304,6 +306,7 @@ int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, con
     lora::effective_weights(shape, params, p.w);
     p.variant = LORA_VARIANT_DIRECT;
     p.generic = odd_inner;
+    p.boundary = g_default_boundary;
     if (nd == 3) {
         // enough workgroups to fill 256 CUs a few times over, chunks as long as that allows
         const long tiles = (long) ((dims[2] + 127) / 128) * ((dims[1] + 15) / 16);
@@ -312,6 +315,10 @@ int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, con
         p.z_chunk = zc;
     }
     lora::plan_refresh(p);
+    if (p.boundary == LORA_BC_PERIODIC && lora_plan_set_boundary(pl, LORA_BC_PERIODIC) != LORA_OK) {
+        delete pl;
+        return LORA_EUNSUPPORTED;
+    }
     *out = pl;
     return LORA_OK;
 }
@@ -331,6 +338,28 @@ int lora_plan_set_weights(lora_plan *plan, const double *weights, int count) {
 int lora_plan_get_weights(const lora_plan *plan, double *weights, int count) {
     if (!plan || !weights || count != plan->p.ntaps) return LORA_EINVAL;
     std::memcpy(weights, plan->p.w, sizeof(double) * count);
+    return LORA_OK;
+}
+
+int lora_set_default_boundary(int boundary) {
+    const int old = g_default_boundary;
+    if (boundary >= LORA_BC_REFERENCE && boundary <= LORA_BC_PERIODIC) g_default_boundary = boundary;
+    return old;
+}
+
+int lora_plan_set_boundary(lora_plan *plan, int boundary) {
+    if (!plan || boundary < LORA_BC_REFERENCE || boundary > LORA_BC_PERIODIC) return LORA_EINVAL;
+    if (boundary == LORA_BC_PERIODIC) {
+        static const int h1[1] = {4}, h2[2] = {4, 4}, h3[3] = {1, 2, 4};
+        const int *h = plan->p.ndim == 1 ? h1 : (plan->p.ndim == 2 ? h2 : h3);
+        for (int d = 0; d < plan->p.ndim; ++d)
+            if (plan->p.dims[d] < h[d]) {
+                g_last_error = "periodic boundary needs every extent >= its halo width";
+                return LORA_EUNSUPPORTED;
+            }
+    }
+    plan->p.boundary = boundary;
+    ++plan->p.epoch;
     return LORA_OK;
 }
 
@@ -402,6 +431,8 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.persistent;
     else if (!std::strcmp(key, "graph"))
         *value = p.use_graph;
+    else if (!std::strcmp(key, "boundary"))
+        *value = p.boundary;
     else if (!std::strcmp(key, "lds_dma"))
         *value = p.lds_dma;
     else if (!std::strcmp(key, "cols_per_lane"))
@@ -462,29 +493,54 @@ int lora_plan_step2(lora_plan *plan, const void *d_in, void *d_out, void *stream
 static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream) {
     Plan &p = plan->p;
     void *buf[2] = {d_buf0, d_buf1};
-    int done = 0;
-    if (p.steps_per_launch == 2 && p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && times >= 4) {
-        // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes the other one,
-        // so while fused launches run BOTH physical buffers carry buffer 0's halo; an even number of them leaves
-        // the data in buffer 0, after which buffer 1's halo is put back to 0 and the remaining 0..3 steps are
-        // single sweeps -- the result and its halo end up exactly where the step-by-step driver leaves them.
-        if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
-        hipStream_t s = static_cast<hipStream_t>(stream);
-        const int pairs = (times / 2) & ~1;
-        hipError_t e = lora::launch_halo_ring_2d(p, static_cast<double *>(d_buf1), static_cast<const double *>(d_buf0), s);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (times == 0) return LORA_OK;
+    auto halo = [&](void *dst, const void *src, int mode, const char *what) -> int {
+        const hipError_t e = lora::launch_halo(p, dst, src, mode, s);
         if (e != hipSuccess) {
-            lora::set_last_error("halo copy", e);
+            lora::set_last_error(what, e);
             return LORA_EHIP;
         }
+        return LORA_OK;
+    };
+    if (p.boundary != LORA_BC_REFERENCE) {
+        if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
+    }
+
+    if (p.boundary == LORA_BC_PERIODIC) {
+        // torus: refresh the source's halo from the opposite interior edges before every sweep, and once more at the
+        // end so that the result is a consistent periodic array (single sweeps: a fused launch would need the wrap
+        // of its intermediate level)
+        for (int i = 0; i < times; ++i) {
+            if (int rc = halo(buf[i % 2], nullptr, lora::HALO_WRAP, "periodic halo")) return rc;
+            if (int rc = lora_plan_step(plan, buf[i % 2], buf[(i + 1) % 2], stream)) return rc;
+        }
+        return halo(buf[times % 2], nullptr, lora::HALO_WRAP, "periodic halo");
+    }
+
+    const bool dirichlet = p.boundary == LORA_BC_DIRICHLET;
+    if (dirichlet) {
+        // fixed halo: both buffers carry the caller's halo for the whole run
+        if (int rc = halo(buf[1], buf[0], lora::HALO_COPY, "halo copy")) return rc;
+    }
+    int done = 0;
+    const bool can_fuse = p.steps_per_launch == 2 && p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && !p.generic;
+    if (can_fuse && times >= 4) {
+        // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes the other one,
+        // so while fused launches run BOTH physical buffers carry buffer 0's halo; an even number of them leaves
+        // the data in buffer 0, after which (reference boundary) buffer 1's halo is put back to 0 and the remaining
+        // 0..3 steps are single sweeps -- the result and its halo end up exactly where the step-by-step driver
+        // leaves them.  With the Dirichlet boundary both halos simply stay.
+        if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
+        const int pairs = (times / 2) & ~1;
+        if (!dirichlet)
+            if (int rc = halo(buf[1], buf[0], lora::HALO_COPY, "halo copy")) return rc;
         for (int k = 0; k < pairs; ++k) {
             const int rc = lora_plan_step2(plan, buf[k % 2], buf[(k + 1) % 2], stream);
             if (rc != LORA_OK) return rc;
         }
-        e = lora::launch_halo_ring_2d(p, static_cast<double *>(d_buf1), nullptr, s);
-        if (e != hipSuccess) {
-            lora::set_last_error("halo reset", e);
-            return LORA_EHIP;
-        }
+        if (!dirichlet)
+            if (int rc = halo(buf[1], nullptr, lora::HALO_ZERO, "halo reset")) return rc;
         done = 2 * pairs;
     }
     for (int i = done; i < times; ++i) {  // 2d/gpu.cu:544-546

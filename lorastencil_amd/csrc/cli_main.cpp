@@ -8,6 +8,7 @@
 //   --check            run the reference's CHECK_ERROR self-check (one sweep against a naive CPU loop, 1e-7 abs)
 //   --fill=random|index|ones   the reference's FILL_RANDOM / FILL_INDEX / default fills (compile-time macros there)
 //   --no-extra         print nothing beyond the reference's own lines
+//   --bc=reference|dirichlet|periodic   boundary condition of the time-step driver (default: the reference's)
 //   --dtype=bf16       (lorastencil_3d only) store the grid in bf16, accumulate in fp32 (BASELINE config 5; new)
 #include <cstdio>
 #include <cstdlib>
@@ -121,7 +122,7 @@ int main(int argc, char *argv[]) {
         return 1;
     }
 
-    bool check = false, extra = true, bf16 = false;
+    bool check = false, extra = true, bf16 = false, custom_bc = false;
     Fill fill = Fill::Random;
     for (int i = kDim + 3; i < argc; ++i) {
         const std::string a = argv[i];
@@ -135,6 +136,12 @@ int main(int argc, char *argv[]) {
             fill = Fill::Index;
         else if (a == "--fill=ones")
             fill = Fill::Ones;
+        else if (a == "--bc=reference")
+            lora_set_default_boundary(LORA_BC_REFERENCE);
+        else if (a == "--bc=dirichlet" || a == "--bc=periodic") {
+            lora_set_default_boundary(a == "--bc=dirichlet" ? LORA_BC_DIRICHLET : LORA_BC_PERIODIC);
+            custom_bc = true;
+        }
         else if (a == "--dtype=f64")
             bf16 = false;
         else if (a == "--dtype=bf16" && kDim == 3)
@@ -171,6 +178,10 @@ int main(int argc, char *argv[]) {
     std::vector<double> matrix(count, 0.0), output(count, 0.0);
     fill_input(matrix, shape, dims, fill);
 
+    if (check && custom_bc) {
+        std::cerr << "--check compares with the reference's boundary behaviour; ignored with --bc\n";
+        check = false;
+    }
     if (check) {  // CHECK_ERROR prints the shape and the params first (2d/main.cu:257-265)
         std::cout << argv[1] << std::endl;
     }

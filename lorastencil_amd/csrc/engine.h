@@ -66,6 +66,7 @@ struct Plan {
     bool lowrank_valid = false;
     LowRank2D lowrank{};
     std::string kernel_name;
+    int boundary = LORA_BC_REFERENCE;  // what halo cells hold between sweeps (lora_plan_set_boundary)
     int use_graph = -1;   // -1 auto (small grids, many launches, non-default stream), 0 never, 1 whenever possible
     unsigned epoch = 0;   // bumped by every change of taps / options: invalidates a cached graph
 };
@@ -79,8 +80,9 @@ hipError_t launch_2d_direct(const Plan &p, const double *in, double *out, int be
 hipError_t launch_2d_mfma(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 // two applications per launch (intermediate level in LDS, its halo = 0); 2D direct taps only
 hipError_t launch_2d_fused2(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
-// halo ring of a padded 2D array: dst <- src, or dst <- 0 when src == nullptr
-hipError_t launch_halo_ring_2d(const Plan &p, double *dst, const double *src, hipStream_t s);
+// halo cells of a padded array (any shape / element type): copy from src, zero, or periodic wrap from dst itself
+enum HaloMode { HALO_COPY = 0, HALO_ZERO = 1, HALO_WRAP = 2 };
+hipError_t launch_halo(const Plan &p, void *dst, const void *src, int mode, hipStream_t s);
 const char *kernel_name_2d_fused2(const Plan &p);
 hipError_t launch_3d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 // any size, any taps (odd innermost extents): one thread per point

@@ -42,6 +42,7 @@ struct ArgsFused {
     int ld, m, n;
     int row_begin, row_end;
     int tiles_x, tiles_y, panel_w;
+    int dirichlet;  // intermediate cells outside the interior keep the input halo value instead of 0
 };
 
 // PERSIST: the grid is 3 workgroups per CU; each walks its XCD's run of tiles and fetches the next tile's input
@@ -163,6 +164,16 @@ __global__ __launch_bounds__(256, 3) void stencil2d_fused2_kernel(const ArgsFuse
             for (int r = 0; r < R1; ++r) {
                 if (j - r >= 0 && j - r < 7) asm volatile("" : "+v"(acc0[r]), "+v"(acc1[r]));
             }
+            if (a.dirichlet && j >= 6) {
+                // Dirichlet boundary: an intermediate cell outside the interior is a halo cell that keeps the
+                // caller's value, which is the cell itself in the input window (3 rows / columns further in A)
+                const int r = j - 6;
+                const int im = i0 - 3 + wv * R1 + r;
+                const bool row_in = im >= 0 && im < a.m;
+                const double *cell = A + (wv * R1 + r + 3) * kInW + 2 * lane + 3;
+                if (!(row_in && c0_in)) acc0[r] = cell[0];
+                if (!(row_in && c1_in)) acc1[r] = cell[1];
+            }
 #pragma unroll
             for (int q = 0; q < 4; ++q) cur[q] = nxt[q];
             __builtin_amdgcn_sched_barrier(0);
@@ -174,8 +185,8 @@ __global__ __launch_bounds__(256, 3) void stencil2d_fused2_kernel(const ArgsFuse
             const bool row_in = im >= 0 && im < a.m;
             d2 v;
             // cells outside the interior are halo cells of "buffer 1": never written, always 0
-            v.x = (row_in && c0_in) ? acc0[r] : 0.0;
-            v.y = (row_in && c1_in) ? acc1[r] : 0.0;
+            v.x = (a.dirichlet || (row_in && c0_in)) ? acc0[r] : 0.0;
+            v.y = (a.dirichlet || (row_in && c1_in)) ? acc1[r] : 0.0;
             *reinterpret_cast<d2 *>(B + (wv * R1 + r) * kMidW + 2 * lane) = v;
         }
     }
@@ -245,27 +256,6 @@ __global__ __launch_bounds__(256, 3) void stencil2d_fused2_kernel(const ArgsFuse
     }  // tile loop
 }
 
-// Halo ring of a padded (m+8) x (n+8) array: dst <- src (src != nullptr) or dst <- 0.
-__global__ void halo_ring_kernel(double *__restrict__ dst, const double *__restrict__ src, int m, int n) {
-    const long ld = n + 8;
-    const long top = 4 * ld;             // rows 0..3 and rows m+4..m+7: full rows
-    const long side = (long) m * 8;      // rows 4..m+3: columns 0..3 and n+4..n+7
-    const long total = 2 * top + side;
-    for (long k = (long) blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long) gridDim.x * blockDim.x) {
-        long off;
-        if (k < top) {
-            off = k;
-        } else if (k < 2 * top) {
-            off = (long) (m + 4) * ld + (k - top);
-        } else {
-            const long s = k - 2 * top;
-            const long r = s >> 3, c = s & 7;
-            off = (r + 4) * ld + (c < 4 ? c : n + c);
-        }
-        dst[off] = src ? src[off] : 0.0;
-    }
-}
-
 template <int TAPSET, int R1>
 hipError_t launch_fused2_t(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
     constexpr int TH = 4 * R1 - 6;
@@ -280,6 +270,7 @@ hipError_t launch_fused2_t(const Plan &p, const double *in, double *out, int beg
     a.tiles_x = (a.n + kOutW - 1) / kOutW;
     a.tiles_y = (end - begin + TH - 1) / TH;
     a.panel_w = p.panel_width < 1 ? 1 : (p.panel_width > a.tiles_x ? a.tiles_x : p.panel_width);
+    a.dirichlet = p.boundary == LORA_BC_DIRICHLET;
     Taps49 w;
     for (int k = 0; k < 49; ++k) w.w[k] = p.w[k];
     const long nblocks = (long) a.tiles_x * a.tiles_y;
@@ -317,13 +308,6 @@ hipError_t launch_2d_fused2(const Plan &p, const double *in, double *out, int be
     if (p.fused_rows == 10) { LORA_FUSED_DISPATCH(10) }
     LORA_FUSED_DISPATCH(8)
 #undef LORA_FUSED_DISPATCH
-}
-
-hipError_t launch_halo_ring_2d(const Plan &p, double *dst, const double *src, hipStream_t s) {
-    const long total = 8L * (p.dims[1] + 8) + 8L * p.dims[0];
-    const int blocks = (int) ((total + 255) / 256 > 1024 ? 1024 : (total + 255) / 256);
-    hipLaunchKernelGGL(halo_ring_kernel, dim3(blocks), dim3(256), 0, s, dst, src, p.dims[0], p.dims[1]);
-    return hipGetLastError();
 }
 
 const char *kernel_name_2d_fused2(const Plan &) { return "stencil2d_fused2_kernel"; }

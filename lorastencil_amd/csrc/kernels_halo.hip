@@ -1,0 +1,123 @@
+// kernels_halo.hip -- halo-cell kernels of the time-step driver (O(surface) work, never on the sweep's critical path).
+//
+// The reference never writes halo cells (2d/gpu.cu:266-271), which gives it the alternating boundary condition of
+// SURVEY B2.  The driver here needs three halo operations on a padded array:
+//   COPY  dst halo <- src halo   (temporal fusion keeps the level-0 halo in both buffers; Dirichlet boundary)
+//   ZERO  dst halo <- 0          (restore the state of the reference's second buffer)
+//   WRAP  dst halo <- the opposite interior edge of dst itself (periodic boundary, all dimensions at once:
+//                                 every halo cell reads the interior cell it is a periodic image of)
+// Halo widths follow the reference layouts: 4 (1D), 4 x 4 (2D), 1 x 2 x 4 (3D, 3d/main.cu:21-23).
+#include <hip/hip_runtime.h>
+
+#include "engine.h"
+
+namespace lora {
+
+namespace {
+
+struct HaloArgs {
+    int nd;
+    long ext[3];   // interior extents, outermost first (unused dims = 1)
+    long halo[3];  // halo width per dimension (unused dims = 0)
+    long region_end[6];
+};
+
+// Decode the k-th halo cell of a padded box into padded coordinates.  Regions, outermost dimension first:
+// low and high slabs of dim 0 (full cross-section), then within the dim-0 interior the low/high slabs of dim 1
+// (full dim-2 width), then within the dim-0/1 interior the low/high strips of dim 2.
+__device__ __forceinline__ bool decode(const HaloArgs &a, long k, long c[3]) {
+    const long P0 = a.ext[0] + 2 * a.halo[0], P1 = a.ext[1] + 2 * a.halo[1], P2 = a.ext[2] + 2 * a.halo[2];
+    (void) P0;
+    // region 0: dim-0 slabs: 2*halo0 x P1 x P2
+    const long r0 = 2 * a.halo[0] * P1 * P2;
+    if (k < r0) {
+        const long s = k / (P1 * P2), rem = k - s * (P1 * P2);
+        c[0] = s < a.halo[0] ? s : a.ext[0] + s;  // s in [halo0, 2 halo0) -> padded ext0 + s
+        c[1] = rem / P2;
+        c[2] = rem - c[1] * P2;
+        return true;
+    }
+    k -= r0;
+    // region 1: dim-1 slabs inside the dim-0 interior: ext0 x 2*halo1 x P2
+    const long r1 = a.ext[0] * 2 * a.halo[1] * P2;
+    if (k < r1) {
+        const long i0 = k / (2 * a.halo[1] * P2), rem = k - i0 * (2 * a.halo[1] * P2);
+        const long s = rem / P2;
+        c[0] = i0 + a.halo[0];
+        c[1] = s < a.halo[1] ? s : a.ext[1] + s;
+        c[2] = rem - s * P2;
+        return true;
+    }
+    k -= r1;
+    // region 2: dim-2 strips inside the dim-0/1 interior: ext0 x ext1 x 2*halo2
+    const long r2 = a.ext[0] * a.ext[1] * 2 * a.halo[2];
+    if (k < r2) {
+        const long w = 2 * a.halo[2];
+        const long i0 = k / (a.ext[1] * w), rem = k - i0 * (a.ext[1] * w);
+        const long i1 = rem / w, s = rem - i1 * w;
+        c[0] = i0 + a.halo[0];
+        c[1] = i1 + a.halo[1];
+        c[2] = s < a.halo[2] ? s : a.ext[2] + s;
+        return true;
+    }
+    return false;
+}
+
+template <typename T>
+__global__ void halo_kernel(T *__restrict__ dst, const T *__restrict__ src, const HaloArgs a, int mode, long total) {
+    const long P1 = a.ext[1] + 2 * a.halo[1], P2 = a.ext[2] + 2 * a.halo[2];
+    for (long k = (long) blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long) gridDim.x * blockDim.x) {
+        long c[3];
+        if (!decode(a, k, c)) continue;
+        const long off = (c[0] * P1 + c[1]) * P2 + c[2];
+        if (mode == HALO_ZERO) {
+            dst[off] = T(0);
+        } else if (mode == HALO_COPY) {
+            dst[off] = src[off];
+        } else {  // HALO_WRAP: the interior cell this halo cell is the periodic image of
+            long w[3];
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                long x = c[d];
+                if (x < a.halo[d])
+                    x += a.ext[d];
+                else if (x >= a.halo[d] + a.ext[d])
+                    x -= a.ext[d];
+                w[d] = x;
+            }
+            dst[off] = dst[(w[0] * P1 + w[1]) * P2 + w[2]];
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_halo(const Plan &p, void *dst, const void *src, int mode, hipStream_t s) {
+    HaloArgs a;
+    a.nd = p.ndim;
+    // map the shape's dims onto a 3-level box: unused leading dimensions have extent 1 and no halo
+    const long h1[1] = {4}, h2[2] = {4, 4}, h3[3] = {1, 2, 4};
+    const long *h = p.ndim == 1 ? h1 : (p.ndim == 2 ? h2 : h3);
+    for (int d = 0; d < 3; ++d) {
+        const int sd = d - (3 - p.ndim);  // index into the shape's own dims
+        a.ext[d] = sd >= 0 ? p.dims[sd] : 1;
+        a.halo[d] = sd >= 0 ? h[sd] : 0;
+    }
+    if (mode == HALO_WRAP)
+        for (int d = 0; d < 3; ++d)
+            if (a.halo[d] > a.ext[d]) return hipErrorInvalidValue;  // the wrap source would be a halo cell itself
+    const long P1 = a.ext[1] + 2 * a.halo[1], P2 = a.ext[2] + 2 * a.halo[2];
+    const long total = 2 * a.halo[0] * P1 * P2 + a.ext[0] * 2 * a.halo[1] * P2 + a.ext[0] * a.ext[1] * 2 * a.halo[2];
+    if (total <= 0) return hipSuccess;
+    const long want = (total + 255) / 256;
+    const int blocks = (int) (want > 4096 ? 4096 : want);
+    if (p.dtype == LORA_BF16)
+        hipLaunchKernelGGL(halo_kernel<unsigned short>, dim3(blocks), dim3(256), 0, s, static_cast<unsigned short *>(dst),
+                           static_cast<const unsigned short *>(src), a, mode, total);
+    else
+        hipLaunchKernelGGL(halo_kernel<double>, dim3(blocks), dim3(256), 0, s, static_cast<double *>(dst),
+                           static_cast<const double *>(src), a, mode, total);
+    return hipGetLastError();
+}
+
+}  // namespace lora

@@ -157,6 +157,7 @@ def reference_input(shape, dims, rng: GlibcRand | None = None) -> np.ndarray:
     return rng.fill(int(np.prod(ps)), 100).reshape(ps)
 
 
+BOUNDARIES = {"reference": _lib.BC_REFERENCE, "dirichlet": _lib.BC_DIRICHLET, "periodic": _lib.BC_PERIODIC}
 DTYPES = {"f64": _lib.F64, "fp64": _lib.F64, "float64": _lib.F64, "bf16": _lib.BF16, "bfloat16": _lib.BF16}
 
 
@@ -311,6 +312,12 @@ class Plan:
 
     def set_variant(self, variant: int):
         check(_lib.lib().lora_plan_set_variant(self._h, int(variant)), "lora_plan_set_variant")
+        return self
+
+    def set_boundary(self, boundary):
+        """"reference" (default: halo never written), "dirichlet" (halo fixed) or "periodic" -- applied by run()."""
+        b = BOUNDARIES[boundary] if isinstance(boundary, str) else int(boundary)
+        check(_lib.lib().lora_plan_set_boundary(self._h, b), "lora_plan_set_boundary")
         return self
 
     def set_option(self, key: str, value: int):

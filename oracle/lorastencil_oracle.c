@@ -439,3 +439,77 @@ int oracle_run_bf16(int shape, const uint16_t *in, uint16_t *out, const double *
     free(buf[1]);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------------
+ * Boundary-condition options (not reference behaviour; see header)
+ * ---------------------------------------------------------------------------------------- */
+static void shape_geometry(int shape, const int *dims, int *nd, long ext[3], long hw[3]) {
+    static const long h1[1] = {4}, h2[2] = {4, 4}, h3[3] = {1, 2, 4};
+    *nd = shape_dim(shape);
+    const long *h = *nd == 1 ? h1 : (*nd == 2 ? h2 : h3);
+    for (int d = 0; d < 3; d++) {
+        const int sd = d - (3 - *nd);
+        ext[d] = sd >= 0 ? dims[sd] : 1;
+        hw[d] = sd >= 0 ? h[sd] : 0;
+    }
+}
+
+/* mode 0: dst halo <- src halo; mode 2: dst halo <- periodic image inside dst */
+static void halo_apply(double *dst, const double *src, const long ext[3], const long hw[3], int wrap) {
+    const long P0 = ext[0] + 2 * hw[0], P1 = ext[1] + 2 * hw[1], P2 = ext[2] + 2 * hw[2];
+    for (long a = 0; a < P0; a++)
+        for (long b = 0; b < P1; b++)
+            for (long c = 0; c < P2; c++) {
+                const int inside = a >= hw[0] && a < hw[0] + ext[0] && b >= hw[1] && b < hw[1] + ext[1] &&
+                                   c >= hw[2] && c < hw[2] + ext[2];
+                if (inside) continue;
+                const long off = (a * P1 + b) * P2 + c;
+                if (!wrap) {
+                    dst[off] = src[off];
+                } else {
+                    long w[3] = {a, b, c};
+                    for (int d = 0; d < 3; d++) {
+                        if (w[d] < hw[d])
+                            w[d] += ext[d];
+                        else if (w[d] >= hw[d] + ext[d])
+                            w[d] -= ext[d];
+                    }
+                    dst[off] = dst[(w[0] * P1 + w[1]) * P2 + w[2]];
+                }
+            }
+}
+
+int oracle_run_bc(int shape, const double *in, double *out, const double *w, int times, const int *dims, int bc,
+                  int threads) {
+    if (bc == ORACLE_BC_REFERENCE) return oracle_run_weights(shape, in, out, w, times, dims, threads);
+    int nd;
+    long ext[3], hw[3];
+    shape_geometry(shape, dims, &nd, ext, hw);
+    if (nd == 0 || times < 0) return -1;
+    const size_t count = oracle_padded_count(shape, dims);
+    double *buf[2];
+    buf[0] = (double *) malloc(count * sizeof(double));
+    buf[1] = (double *) calloc(count, sizeof(double));
+    if (!buf[0] || !buf[1]) {
+        free(buf[0]);
+        free(buf[1]);
+        return -1;
+    }
+    memcpy(buf[0], in, count * sizeof(double));
+    if (bc == ORACLE_BC_DIRICHLET && times > 0) halo_apply(buf[1], buf[0], ext, hw, 0);
+    for (int i = 0; i < times; i++) {
+        double *src = buf[i % 2], *dst = buf[(i + 1) % 2];
+        if (bc == ORACLE_BC_PERIODIC) halo_apply(src, NULL, ext, hw, 1);
+        if (nd == 1)
+            oracle_step_1d(src, dst, w, dims[0] + 8, threads);
+        else if (nd == 2)
+            oracle_step_2d(src, dst, w, dims[0] + 8, dims[1] + 8, threads);
+        else
+            oracle_step_3d(src, dst, w, dims[0] + 2, dims[1] + 4, dims[2] + 8, threads);
+    }
+    if (bc == ORACLE_BC_PERIODIC && times > 0) halo_apply(buf[times % 2], NULL, ext, hw, 1);
+    memcpy(out, buf[times % 2], count * sizeof(double));
+    free(buf[0]);
+    free(buf[1]);
+    return 0;
+}

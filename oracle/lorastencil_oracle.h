@@ -91,6 +91,15 @@ int oracle_run(int shape, const double *in, double *out, const double *params, i
 int oracle_run_weights(int shape, const double *in, double *out, const double *w, int times, const int *dims,
                        int threads);
 
+/* ---- boundary-condition options of the driver (NOT behaviour of the reference, whose only
+ * boundary condition is ORACLE_BC_REFERENCE = oracle_run_weights; parity for the other two is unpinned by it).
+ *   DIRICHLET: halo cells hold the caller's input values at every time level (buffer 1 starts with buffer 0's halo);
+ *   PERIODIC : before every sweep, and once after the last, each halo cell of the current buffer takes the value of
+ *              the interior cell it is a periodic image of. */
+enum { ORACLE_BC_REFERENCE = 0, ORACLE_BC_DIRICHLET = 1, ORACLE_BC_PERIODIC = 2 };
+int oracle_run_bc(int shape, const double *in, double *out, const double *w, int times, const int *dims, int bc,
+                  int threads);
+
 /* ---- bf16 storage (3D shapes).  PARITY UNPINNED: the reference has no reduced-precision path at all
  * (SURVEY section 2 row 12), so there is nothing of its own to pin this against.  The contract restated here is the
  * one the engine documents (kernels_3d_bf16.hip): bf16 values, fp32 taps, one fp32 fused multiply-add per tap in

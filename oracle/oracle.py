@@ -71,6 +71,8 @@ def lib() -> ctypes.CDLL:
         L.oracle_padded_count.argtypes = [ctypes.c_int, _ip]
         L.oracle_padded_count.restype = ctypes.c_size_t
         L.oracle_max_threads.restype = ctypes.c_int
+        L.oracle_run_bc.argtypes = [ctypes.c_int, _dp, _dp, _dp, ctypes.c_int, _ip, ctypes.c_int, ctypes.c_int]
+        L.oracle_run_bc.restype = ctypes.c_int
         _u16 = ctypes.POINTER(ctypes.c_uint16)
         L.oracle_f32_to_bf16.argtypes = [ctypes.c_float]
         L.oracle_f32_to_bf16.restype = ctypes.c_uint16
@@ -238,4 +240,22 @@ def run_bf16(shape, a_bits: np.ndarray, times: int, weights=None, threads: int =
     rc = lib().oracle_run_bf16(sid, a_bits.ctypes.data_as(u16), out.ctypes.data_as(u16), _p(w), times, dims, threads)
     if rc != 0:
         raise ValueError("oracle_run_bf16 failed")
+    return out
+
+
+BOUNDARIES = {"reference": 0, "dirichlet": 1, "periodic": 2}
+
+
+def run_bc(shape, a: np.ndarray, times: int, bc, weights=None, threads: int = 1) -> np.ndarray:
+    """The driver with a boundary-condition option (not reference behaviour; see lorastencil_oracle.h)."""
+    sid = shape_id(shape)
+    nd = NDIM[sid]
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    w = effective_weights(sid) if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+    h = halo(sid)
+    dims = (ctypes.c_int * 3)(*[a.shape[i] - 2 * h[i] for i in range(nd)], *([0] * (3 - nd)))
+    out = np.zeros_like(a)
+    b = BOUNDARIES[bc] if isinstance(bc, str) else int(bc)
+    if lib().oracle_run_bc(sid, _p(a), _p(out), _p(w), times, dims, b, threads) != 0:
+        raise ValueError("oracle_run_bc failed")
     return out

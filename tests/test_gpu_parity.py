@@ -441,6 +441,50 @@ def test_graph_replay_of_launch_bound_runs(L, O, shape, dims, t):
     assert rel_err(got, exp2) < 1e-13
 
 
+@pytest.mark.parametrize("bc", ["dirichlet", "periodic"])
+@pytest.mark.parametrize("shape,dims", [("star2d1r", (64, 128)), ("star2d1r", (53, 246)), ("box2d3r", (40, 130)),
+                                        ("star2d3r", (200, 380)), ("star3d1r", (9, 20, 136)), ("box3d1r", (6, 5, 8)),
+                                        ("1d1r", (4096,)), ("star2d1r", (33, 65))])
+def test_boundary_condition_options(L, O, shape, dims, bc):
+    """fixed (Dirichlet) and periodic halos as driver options, against the oracle's restatement."""
+    import torch
+
+    a = O.reference_input(shape, dims)
+    for t in (1, 4, 5, 8):
+        plan = L.Plan(shape, dims).set_boundary(bc)
+        b0 = torch.from_numpy(a).cuda()
+        b1 = torch.zeros_like(b0)
+        plan.run(b0, b1, t)
+        torch.cuda.synchronize()
+        got = (b0, b1)[t % 2].cpu().numpy()
+        exp = O.run_bc(shape, a, t, bc)
+        if np.abs(exp).max() < 2.0 ** 53:
+            assert np.array_equal(got, exp), f"{shape} {dims} {bc} t={t}"
+        else:
+            assert rel_err(got, exp) < 1e-13
+
+
+def test_boundary_condition_bf16_and_validation(L, O):
+    shape, dims = "box3d1r", (6, 10, 64)
+    bits = O.to_bf16(O.reference_input(shape, dims))
+    import torch
+
+    plan = L.Plan(shape, dims, dtype="bf16").set_boundary("periodic")
+    w = O.effective_weights(shape) / 36.0
+    plan.set_weights(w)
+    b0 = torch.from_numpy(bits.view(np.int16).copy()).cuda().view(torch.bfloat16)
+    b1 = torch.zeros_like(b0)
+    plan.run(b0, b1, 1)
+    torch.cuda.synchronize()
+    got = O.from_bf16(b1.view(torch.int16).cpu().numpy().view(np.uint16))
+    # one periodic sweep in bf16 tracks the fp64 periodic sweep to bf16 precision, halo = periodic image
+    ref = O.run_bc(shape, O.from_bf16(bits), 1, "periodic", weights=w)
+    assert rel_err(got, ref) < 2.0 ** -7
+    assert np.array_equal(got[0, 2:-2, 4:-4], got[-2, 2:-2, 4:-4])
+    with pytest.raises(L.LoraError):
+        L.Plan("star2d1r", (2, 64)).set_boundary("periodic")  # extent smaller than the halo: no torus
+
+
 def test_halo_cells_are_never_written(L, O):
     import torch
 

@@ -117,3 +117,49 @@ def test_halo_alternation_and_parity():
 def test_threads_do_not_change_results():
     g = load_golden("box3d1r")
     assert np.array_equal(o.run("box3d1r", g["input"], 3, threads=1), o.run("box3d1r", g["input"], 3, threads=4))
+
+
+def test_boundary_options_of_the_oracle_have_the_properties_they_claim():
+    """Dirichlet / periodic are options beyond the reference; nothing of the reference pins them, so the oracle's own
+    restatement is checked against what the words mean."""
+    rng = np.random.default_rng(4)
+    shape, dims = "star2d1r", (12, 20)
+    a = rng.integers(0, 50, o.padded_shape(shape, dims)).astype(np.float64)
+    w = o.effective_weights(shape)
+    halo = np.ones(a.shape, bool)
+    halo[4:-4, 4:-4] = False
+    # reference mode through the same entry point
+    assert np.array_equal(o.run_bc(shape, a, 3, "reference"), o.run(shape, a, 3))
+    # Dirichlet: the halo keeps the caller's values at every level; one sweep equals the reference's first sweep
+    for t in (1, 2, 3):
+        assert np.array_equal(o.run_bc(shape, a, t, "dirichlet")[halo], a[halo])
+    assert np.array_equal(o.interior(shape, o.run_bc(shape, a, 1, "dirichlet")), o.interior(shape, o.run(shape, a, 1)))
+    d2 = o.step(shape, o.run_bc(shape, a, 1, "dirichlet"), w)
+    assert np.array_equal(o.interior(shape, o.run_bc(shape, a, 2, "dirichlet")), o.interior(shape, d2))
+    # periodic: translation invariance on the torus, and equality with an explicit numpy wrap
+    core = o.interior(shape, a)
+    t = 3
+    out = o.interior(shape, o.run_bc(shape, a, t, "periodic"))
+    shifted = a.copy()
+    shifted[4:-4, 4:-4] = np.roll(core, (5, -7), axis=(0, 1))
+    out_s = o.interior(shape, o.run_bc(shape, shifted, t, "periodic"))
+    assert np.array_equal(out_s, np.roll(out, (5, -7), axis=(0, 1)))
+    cur = core.copy()
+    w7 = w.reshape(7, 7)
+    for _ in range(t):
+        nxt = np.zeros_like(cur)
+        for dy in range(7):
+            for dx in range(7):
+                if w7[dy, dx]:
+                    nxt += w7[dy, dx] * np.roll(cur, (3 - dy, 3 - dx), axis=(0, 1))
+        cur = nxt
+    assert np.array_equal(out, cur)
+    # 3D and 1D wraps
+    for shape, dims in (("box3d1r", (3, 4, 6)), ("1d2r", (16,))):
+        a = rng.integers(0, 9, o.padded_shape(shape, dims)).astype(np.float64)
+        out = o.run_bc(shape, a, 2, "periodic")
+        core = o.interior(shape, out)
+        if out.ndim == 1:
+            assert np.array_equal(out[:4], core[-4:]) and np.array_equal(out[-4:], core[:4])
+        else:
+            assert np.array_equal(out[0, 2:-2, 4:-4], core[-1]) and np.array_equal(out[1:-1, 2:-2, :4], core[:, :, -4:])
