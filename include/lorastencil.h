@@ -148,6 +148,8 @@ int lora_last_run_info(lora_run_info *info);
  *    A plan fixes shape, interior dims, weights and kernel variant; it owns no grid memory.
  *    Buffers are PADDED device arrays laid out like the host arrays of group A; `stream` is a
  *    hipStream_t passed as void* (NULL = the null stream).  Calls are asynchronous.
+ *    Different plans may be used from different threads at the same time; one plan must not be (it caches the
+ *    hipGraph of its last run and its options are plain fields).
  * ====================================================================================== */
 typedef struct lora_plan lora_plan;
 

@@ -243,6 +243,8 @@ def _ptr(x) -> int:
 
 
 def _stream(stream) -> int:
+    if isinstance(stream, int):
+        return stream
     if stream is None:
         try:
             import torch

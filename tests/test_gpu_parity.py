@@ -701,3 +701,35 @@ def test_three_rank_slabs_on_one_gpu_equal_single_rank(L, O, shape, dims, times,
     assert np.array_equal(got, exp)
     assert fused == (len(dims) == 2 and dtype == "f64")
     assert ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * (2 if fused else 1) * every
+
+
+def test_rccl_backend_initialises_and_slab_driver_runs_under_it(L, O):
+    """One rank over the real "nccl" (= RCCL) backend: process-group creation with device_id, barrier, all-reduce and
+    a SlabDriver run inside an initialised group.  (Two RCCL ranks need two GPUs; the exchange itself is covered over
+    gloo above.)"""
+    script = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["LORA_ROOT"])
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", os.environ["LORA_PORT"])
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+from lorastencil_amd import slab
+from oracle import oracle as O
+a = O.reference_input("star2d1r", (128, 256))
+drv = slab.SlabDriver("star2d1r", (128, 256), device="cuda:0")
+drv.load_global(a); drv.refresh_ghosts(); drv.run(6)
+torch.cuda.synchronize(); dist.barrier()
+t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+ok = np.array_equal(drv.gather_global().numpy(), O.run("star2d1r", a, 6)) and float(t.item()) == 1.5
+dist.destroy_process_group()
+print("RCCL_OK" if ok else "RCCL_MISMATCH")
+'''
+    import socket
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, LORA_ROOT=ROOT, LORA_PORT=str(port))
+    p = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, env=env)
+    assert "RCCL_OK" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
