@@ -173,6 +173,37 @@ void plan_refresh(Plan &p) {
         else
             p.steps_per_launch = p.steps_per_launch_req == 0 ? 2 : p.steps_per_launch_req;
         p.fused_rows = p.fused_rows_req ? p.fused_rows_req : (p.tapset == TAPS2D_STAR ? 6 : 10);
+        // Low-rank evaluation on the vector pipe inside the fused kernel (kernels_2d_fused.hip, apply_row): taken
+        // when the factors have the support pattern one of its two forms is specialised for.
+        p.fused_eval = p.tapset;
+        p.lowrank_rc = 0.0;
+        if (p.lowrank_valid && p.lowrank_valu != 0 && p.steps_per_launch == 2) {
+            const LowRank2D &lr = p.lowrank;
+            auto outside_zero = [&](int t, int lo) {
+                for (int e = 0; e < 7; ++e)
+                    if ((e < lo || e > 6 - lo) && (lr.u[t][e] != 0.0 || lr.v[t][e] != 0.0)) return false;
+                return true;
+            };
+            if (lr.rank == 1 && lr.nresid == 8 && outside_zero(0, 1)) {
+                // residual must be +c on (+-3, 0), (0, +-3) and -c on (+-2, +-2)
+                double c = 0.0;
+                bool ok = true;
+                for (int k = 0; k < 8 && ok; ++k) {
+                    const int ay = lr.rdy[k] < 0 ? -lr.rdy[k] : lr.rdy[k], ax = lr.rdx[k] < 0 ? -lr.rdx[k] : lr.rdx[k];
+                    const bool tip = (ay == 3 && ax == 0) || (ay == 0 && ax == 3), corner = ay == 2 && ax == 2;
+                    if (!tip && !corner) ok = false;
+                    const double ck = tip ? lr.rw[k] : -lr.rw[k];
+                    if (k == 0) c = ck;
+                    if (ck != c) ok = false;
+                }
+                if (ok) {
+                    p.fused_eval = 3;
+                    p.lowrank_rc = c;
+                }
+            } else if (lr.rank == 3 && lr.nresid == 0 && outside_zero(1, 1) && outside_zero(2, 2)) {
+                p.fused_eval = 4;
+            }
+        }
         p.kernel_name = p.generic ? kernel_name_generic(p)
                         : (p.variant == LORA_VARIANT_MFMA)
                             ? kernel_name_2d_mfma(p)
@@ -396,6 +427,9 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "graph")) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.use_graph = value;
+    } else if (!std::strcmp(key, "lowrank_valu")) {
+        if (value < -1 || value > 1) return LORA_EINVAL;
+        p.lowrank_valu = value;
     } else if (!std::strcmp(key, "lds_dma")) {
         p.lds_dma = value ? 1 : 0;
     } else if (!std::strcmp(key, "cols_per_lane")) {
@@ -433,6 +467,10 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.use_graph;
     else if (!std::strcmp(key, "boundary"))
         *value = p.boundary;
+    else if (!std::strcmp(key, "fused_eval"))
+        *value = p.fused_eval;
+    else if (!std::strcmp(key, "lowrank_valu"))
+        *value = p.lowrank_valu;
     else if (!std::strcmp(key, "lds_dma"))
         *value = p.lds_dma;
     else if (!std::strcmp(key, "cols_per_lane"))

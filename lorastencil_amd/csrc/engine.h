@@ -63,6 +63,9 @@ struct Plan {
     int steps_per_launch_req = 0;  // 0 = auto (fused for the diamond / star tap sets), 1, 2
     int steps_per_launch = 1;      // resolved
     bool generic = false;  // odd innermost extent: rows are only 8-byte aligned, the tiled kernels do not apply
+    int lowrank_valu = -1;    // 2D fused: low-rank evaluation on the vector pipe: -1 auto, 0 off, 1 on when the factors fit
+    int fused_eval = 0;       // resolved: 0 = direct taps of `tapset`, 3 = low-rank diamond, 4 = low-rank pyramid
+    double lowrank_rc = 0.0;  // weight of the diamond form's 8-point correction
     bool lowrank_valid = false;
     LowRank2D lowrank{};
     std::string kernel_name;

@@ -36,6 +36,80 @@ constexpr int kMidW = 128;            // intermediate columns per tile
 constexpr int kInW = 136;             // staged input columns per tile
 constexpr int kInChunks = kInW / 2;   // 16-byte chunks per staged row
 
+// Evaluation of one input row's contribution: EVAL 0..2 = direct taps of the diamond / star / box tap set;
+// EVAL_LR_* = the paper's low-rank form on the VECTOR pipe: per factor term t a horizontal pass h_t = v_t * row (once
+// per input row and column), then u_t[dy] h_t scattered to the output rows -- (|v_t| + |u_t|) instead of
+// |u_t| |v_t| multiply-adds per column.  With the reference's factors that is 34 instead of 50 operations per input
+// row for star2d1r (rank 1 on the support 1..5 plus its 8-point correction, 2d/gpu.cu:486-487, :249-264) and 60
+// instead of 98 for the box tables (pyramid terms live on the nested supports 0..6, 1..5, 2..4, 2d/gpu.cu:280-350).
+enum { EVAL_LR_DIAMOND = 3, EVAL_LR_PYRAMID = 4 };
+
+struct LowRankTaps {
+    double u[3][7];  // vertical profiles
+    double v[3][7];  // horizontal profiles
+    double rc;       // LR_DIAMOND: +rc on the four axis tips, -rc on the four (+-2, +-2) corners
+};
+
+template <int EVAL, int R>
+__device__ __forceinline__ void apply_row(const int j, const double (&win)[8], double (&acc0)[R], double (&acc1)[R],
+                                          const Taps49 &W, const LowRankTaps &F) {
+    if constexpr (EVAL <= TAPS2D_BOX) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int dy = j - r;
+            if (dy >= 0 && dy < 7) {
+#pragma unroll
+                for (int dx = 0; dx < 7; ++dx) {
+                    if (tap_on<EVAL>(dy, dx)) {
+                        const double wt = W.w[dy * 7 + dx];
+                        acc0[r] = fma(wt, win[dx], acc0[r]);
+                        acc1[r] = fma(wt, win[dx + 1], acc1[r]);
+                    }
+                }
+            }
+        }
+    } else {
+        constexpr int NT = (EVAL == EVAL_LR_DIAMOND) ? 1 : 3;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int lo = (EVAL == EVAL_LR_DIAMOND) ? 1 : t, hi = 6 - lo;  // support of term t, both directions
+            double h0 = F.v[t][lo] * win[lo], h1 = F.v[t][lo] * win[lo + 1];
+#pragma unroll
+            for (int dx = lo + 1; dx <= hi; ++dx) {
+                h0 = fma(F.v[t][dx], win[dx], h0);
+                h1 = fma(F.v[t][dx], win[dx + 1], h1);
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int dy = j - r;
+                if (dy >= lo && dy <= hi) {
+                    acc0[r] = fma(F.u[t][dy], h0, acc0[r]);
+                    acc1[r] = fma(F.u[t][dy], h1, acc1[r]);
+                }
+            }
+        }
+        if constexpr (EVAL == EVAL_LR_DIAMOND) {
+            // the 8-point correction, sharing the sums of mirrored taps between the rows that use them
+            const double s06_0 = win[0] + win[6], s06_1 = win[1] + win[7];  // (dy = 3, dx = 0 and 6)
+            const double s15_0 = win[1] + win[5], s15_1 = win[2] + win[6];  // (dy = 1 or 5, dx = 1 and 5)
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                const int dy = j - r;
+                if (dy == 0 || dy == 6) {
+                    acc0[r] = fma(F.rc, win[3], acc0[r]);
+                    acc1[r] = fma(F.rc, win[4], acc1[r]);
+                } else if (dy == 3) {
+                    acc0[r] = fma(F.rc, s06_0, acc0[r]);
+                    acc1[r] = fma(F.rc, s06_1, acc1[r]);
+                } else if (dy == 1 || dy == 5) {
+                    acc0[r] = fma(-F.rc, s15_0, acc0[r]);
+                    acc1[r] = fma(-F.rc, s15_1, acc1[r]);
+                }
+            }
+        }
+    }
+}
+
 struct ArgsFused {
     const double *in;
     double *out;
@@ -49,7 +123,7 @@ struct ArgsFused {
 // window into registers while the current tile is being computed, so the HBM latency of a tile is hidden behind
 // the two applications of the previous one instead of behind the other resident workgroup only.
 template <int TAPSET, int R1, bool PERSIST>
-__global__ __launch_bounds__(256, 3) void stencil2d_fused2_kernel(const ArgsFused a, const Taps49 W) {
+__global__ __launch_bounds__(256, 3) void stencil2d_fused2_kernel(const ArgsFused a, const Taps49 W, const LowRankTaps F) {
     constexpr int IH = 4 * R1;            // intermediate rows
     constexpr int TH = IH - 6;            // output rows
     constexpr int AH = IH + 6;            // input rows
@@ -146,20 +220,7 @@ __global__ __launch_bounds__(256, 3) void stencil2d_fused2_kernel(const ArgsFuse
                 win[2 * q] = cur[q].x;
                 win[2 * q + 1] = cur[q].y;
             }
-#pragma unroll
-            for (int r = 0; r < R1; ++r) {
-                const int dy = j - r;
-                if (dy >= 0 && dy < 7) {
-#pragma unroll
-                    for (int dx = 0; dx < 7; ++dx) {
-                        if (tap_on<TAPSET>(dy, dx)) {
-                            const double wt = W.w[dy * 7 + dx];
-                            acc0[r] = fma(wt, win[dx], acc0[r]);
-                            acc1[r] = fma(wt, win[dx + 1], acc1[r]);
-                        }
-                    }
-                }
-            }
+            apply_row<TAPSET, R1>(j, win, acc0, acc1, W, F);
 #pragma unroll
             for (int r = 0; r < R1; ++r) {
                 if (j - r >= 0 && j - r < 7) asm volatile("" : "+v"(acc0[r]), "+v"(acc1[r]));
@@ -218,20 +279,7 @@ __global__ __launch_bounds__(256, 3) void stencil2d_fused2_kernel(const ArgsFuse
                 win[2 * q] = cur[q].x;
                 win[2 * q + 1] = cur[q].y;
             }
-#pragma unroll
-            for (int r = 0; r < R2; ++r) {
-                const int dy = j - r;
-                if (dy >= 0 && dy < 7) {
-#pragma unroll
-                    for (int dx = 0; dx < 7; ++dx) {
-                        if (tap_on<TAPSET>(dy, dx)) {
-                            const double wt = W.w[dy * 7 + dx];
-                            acc0[r] = fma(wt, win[dx], acc0[r]);
-                            acc1[r] = fma(wt, win[dx + 1], acc1[r]);
-                        }
-                    }
-                }
-            }
+            apply_row<TAPSET, R2>(j, win, acc0, acc1, W, F);
 #pragma unroll
             for (int r = 0; r < R2; ++r) {
                 if (j - r >= 0 && j - r < 7) asm volatile("" : "+v"(acc0[r]), "+v"(acc1[r]));
@@ -273,6 +321,13 @@ hipError_t launch_fused2_t(const Plan &p, const double *in, double *out, int beg
     a.dirichlet = p.boundary == LORA_BC_DIRICHLET;
     Taps49 w;
     for (int k = 0; k < 49; ++k) w.w[k] = p.w[k];
+    LowRankTaps f{};
+    for (int t = 0; t < 3; ++t)
+        for (int e = 0; e < 7; ++e) {
+            f.u[t][e] = p.lowrank.u[t][e];
+            f.v[t][e] = p.lowrank.v[t][e];
+        }
+    f.rc = p.lowrank_rc;
     const long nblocks = (long) a.tiles_x * a.tiles_y;
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
@@ -285,9 +340,9 @@ hipError_t launch_fused2_t(const Plan &p, const double *in, double *out, int beg
         }
         long grid = 3L * cus;
         if (grid > nblocks) grid = nblocks;
-        hipLaunchKernelGGL((stencil2d_fused2_kernel<TAPSET, R1, true>), dim3((unsigned) grid), dim3(256), 0, s, a, w);
+        hipLaunchKernelGGL((stencil2d_fused2_kernel<TAPSET, R1, true>), dim3((unsigned) grid), dim3(256), 0, s, a, w, f);
     } else {
-        hipLaunchKernelGGL((stencil2d_fused2_kernel<TAPSET, R1, false>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
+        hipLaunchKernelGGL((stencil2d_fused2_kernel<TAPSET, R1, false>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w, f);
     }
     return hipGetLastError();
 }
@@ -296,6 +351,8 @@ hipError_t launch_fused2_t(const Plan &p, const double *in, double *out, int beg
 
 hipError_t launch_2d_fused2(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
 #define LORA_FUSED_DISPATCH(R1)                                                        \
+    if (p.fused_eval == EVAL_LR_DIAMOND) return launch_fused2_t<EVAL_LR_DIAMOND, R1>(p, in, out, begin, end, s); \
+    if (p.fused_eval == EVAL_LR_PYRAMID) return launch_fused2_t<EVAL_LR_PYRAMID, R1>(p, in, out, begin, end, s); \
     switch (p.tapset) {                                                                 \
         case TAPS2D_DIAMOND:                                                            \
             return launch_fused2_t<TAPS2D_DIAMOND, R1>(p, in, out, begin, end, s);     \

@@ -240,6 +240,37 @@ def test_fused_tile_heights(L, O, rows):
         assert np.array_equal(got, O.run(shape, a, 4)), (shape, rows)
 
 
+def test_fused_lowrank_evaluation_on_the_vector_pipe(L, O):
+    """The fused kernel evaluates star2d1r / box tables through their low-rank factors (horizontal pass per term,
+    then vertical scatter) when the factors fit; forcing the direct taps must give the same grid."""
+    import torch
+
+    for shape, expect_eval in (("star2d1r", 3), ("box2d3r", 4), ("box2d1r", 4), ("star2d3r", 1)):
+        dims = (150, 380)
+        a = O.reference_input(shape, dims)
+        exp = O.run(shape, a, 4)
+        plan = L.Plan(shape, dims)
+        assert plan.get_option("fused_eval") == expect_eval, shape
+        assert np.array_equal(plan_run(L, shape, a, 4), exp), shape
+        assert np.array_equal(plan_run(L, shape, a, 4, options={"lowrank_valu": 0}), exp), shape
+        off = L.Plan(shape, dims).set_option("lowrank_valu", 0)
+        assert off.get_option("fused_eval") == {"star2d1r": 0, "box2d3r": 2, "box2d1r": 2, "star2d3r": 1}[shape]
+    # scaled star2d1r taps keep the form; real-valued data within rounding of the oracle
+    rng = np.random.default_rng(8)
+    a = rng.standard_normal(O.padded_shape("star2d1r", (128, 512)))
+    w = O.effective_weights("star2d1r") / 100.0
+    plan = L.Plan("star2d1r", (128, 512)).set_weights(w)
+    assert plan.get_option("fused_eval") == 3
+    assert rel_err(plan_run(L, "star2d1r", a, 8, weights=w), O.run("star2d1r", a, 8, weights=w)) < 1e-13
+    # a rank-4 box table (centre 10): the residual tap rules the pyramid form out, direct taps are used
+    p4 = O.default_params("box2d3r").copy()
+    p4[24] = 10.0
+    plan = L.Plan("box2d3r", (64, 128)).set_weights(p4 / p4.sum())
+    assert plan.get_option("fused_eval") == 2
+    # general taps: direct
+    assert L.Plan("box2d3r", (64, 128)).set_weights(rng.standard_normal(49)).get_option("fused_eval") == 2
+
+
 def test_fused_step2_direct_call_and_regions(L, O):
     import torch
 
@@ -696,9 +727,16 @@ def test_three_rank_slabs_on_one_gpu_equal_single_rank(L, O, shape, dims, times,
     a = O.reference_input(shape, dims)
     if dtype == "bf16":
         exp = O.run_bf16(shape, O.to_bf16(a), times)
+        assert np.array_equal(got, exp)
     else:
+        # N ranks == 1 rank bit-for-bit (same kernels, same per-point arithmetic whatever the decomposition) ...
+        assert np.array_equal(got, plan_run(L, shape, a, times))
+        # ... and equal to the oracle: exactly while the values are exact integers, to rounding beyond 2^53
         exp = O.run(shape, a, times)
-    assert np.array_equal(got, exp)
+        if np.abs(exp).max() < 2.0 ** 53:
+            assert np.array_equal(got, exp)
+        else:
+            assert rel_err(got, exp) < 1e-13
     assert fused == (len(dims) == 2 and dtype == "f64")
     assert ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * (2 if fused else 1) * every
 

@@ -52,9 +52,8 @@ def main():
     del a, b
 
     cases = [
-        ("star2d1r", (16384, 16384), {"steps_per_launch": [2], "panel_width": [16, 32, 64], "fused_rows": [6, 8, 10]}),
-        ("box2d3r", (8192, 8192), {"steps_per_launch": [2], "panel_width": [32], "fused_rows": [6, 8, 10]}),
-        ("star2d3r", (16384, 16384), {"steps_per_launch": [2], "panel_width": [32], "fused_rows": [6, 8, 10]}),
+        ("star2d1r", (16384, 16384), {"steps_per_launch": [2], "lowrank_valu": [0, 1], "fused_rows": [6, 8, 10]}),
+        ("box2d3r", (8192, 8192), {"steps_per_launch": [2], "lowrank_valu": [0, 1], "fused_rows": [6, 8, 10]}),
         ("star2d1r", (16384, 16384), {"rows_per_thread": [4, 8], "panel_width": [16, 32], "variant": [1]}),
         ("star2d1r", (16384, 16384), {"panel_width": [16, 32], "variant": [2]}),
         ("box2d3r", (8192, 8192), {"rows_per_thread": [4, 8], "panel_width": [8, 16, 32, 64], "variant": [1]}),
