@@ -628,6 +628,40 @@ def test_full_size_constant_field_and_windows(L, O, shape, dims):
     assert bool((dst2 == 2.0 * dst).all())
 
 
+def test_full_size_bf16_box3d1r_768(L, O):
+    """BASELINE.json configs[4] at full size: box3d1r 768^3 in bf16 (constant-field identities that are exact in
+    bf16, and sampled windows of a random field compared bit-for-bit with the bf16 oracle)."""
+    import torch
+
+    shape, dims = "box3d1r", (768, 768, 768)
+    ps = L.padded_shape(shape, dims)
+    plan = L.Plan(shape, dims, dtype="bf16")
+    b0 = torch.ones(ps, dtype=torch.bfloat16, device="cuda")
+    b1 = torch.zeros_like(b0)
+    plan.run(b0, b1, 2)
+    torch.cuda.synchronize()
+    assert bool((b1[1:-1, 2:-2, 4:-4] == 36.0).all())        # sum of the taps, exact in bf16
+    assert bool((b0[2:-2, 3:-3, 5:-5] == 1296.0).all())      # 36^2 = 1.010001b x 2^10, still exact
+    assert float(b0[1:-1, 2:-2, 4:-4].float().min()) < 1296.0  # the zero halo of buffer 1 was read at the edge
+    del b0, b1
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    src = torch.randint(0, 100, ps, generator=gen, device="cuda").to(torch.bfloat16)
+    dst = torch.zeros_like(src)
+    plan.step(src, dst)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(1)
+    win = (5, 18, 264)
+    corners = [(0, 0, 0), tuple(d - w for d, w in zip(dims, win))]
+    corners += [tuple(int(rng.integers(0, d - w)) for d, w in zip(dims, win)) for _ in range(5)]
+    w27 = O.effective_weights(shape)
+    for c in corners:
+        sl = tuple(slice(ci, ci + wd + 2 * k) for ci, wd, k in zip(c, win, (1, 2, 4)))
+        sub = src[sl].contiguous().view(torch.int16).cpu().numpy().view(np.uint16)
+        exp = O.run_bf16(shape, sub, 1, weights=w27)[1:-1, 2:-2, 4:-4]
+        got = dst[sl].contiguous().view(torch.int16).cpu().numpy().view(np.uint16)[1:-1, 2:-2, 4:-4]
+        assert np.array_equal(got, exp), f"window at {c}"
+
+
 # ---------------------------------------------------------------------------------------------------------
 # the CLIs and the reference's own harness (oracle/_ref) on top of the HIP engine
 # ---------------------------------------------------------------------------------------------------------

@@ -163,3 +163,16 @@ def test_boundary_options_of_the_oracle_have_the_properties_they_claim():
             assert np.array_equal(out[:4], core[-4:]) and np.array_equal(out[-4:], core[:4])
         else:
             assert np.array_equal(out[0, 2:-2, 4:-4], core[-1]) and np.array_equal(out[1:-1, 2:-2, :4], core[:, :, -4:])
+
+
+@pytest.mark.skipif(not ref.available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_baseline_config0_1d1r_2pow20_100_steps_cpu_path():
+    """BASELINE.json configs[0]: `lorastencil_1d 1d1r 1048576 100`, the CPU-runnable plumbing case: the oracle's
+    driver against 100 chained sweeps of the reference's own test_cpu, bit for bit (values leave the exact-integer
+    range after ~13 steps, so this also pins the rounding of every later step)."""
+    n, t = 1 << 20, 100
+    a = o.reference_input("1d1r", (n,))
+    p = o.default_params("1d1r")
+    exp = ref.run_chain(a, p, t)
+    got = o.run("1d1r", a, t, threads=o.max_threads())
+    assert np.isfinite(exp).all() and np.array_equal(got[:-1], exp[:-1])
