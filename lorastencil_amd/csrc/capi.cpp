@@ -777,28 +777,6 @@ int lora_run_host_dtype(int shape, int dtype, const void *in, void *out, const d
     return LORA_OK;
 }
 
-// host-side bf16 conversion (round-to-nearest-even; NaN stays a quiet NaN)
-static uint16_t f32_to_bf16_bits(float f) {
-    uint32_t u;
-    std::memcpy(&u, &f, 4);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t) ((u >> 16) | 0x0040u);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t) (u >> 16);
-}
-
-void lora_f64_to_bf16(const double *src, uint16_t *dst, size_t count) {
-    for (size_t i = 0; i < count; ++i) dst[i] = f32_to_bf16_bits((float) src[i]);
-}
-
-void lora_bf16_to_f64(const uint16_t *src, double *dst, size_t count) {
-    for (size_t i = 0; i < count; ++i) {
-        const uint32_t u = (uint32_t) src[i] << 16;
-        float f;
-        std::memcpy(&f, &u, 4);
-        dst[i] = f;
-    }
-}
-
 int lora_last_run_info(lora_run_info *info) {
     if (!info) return LORA_EINVAL;
     *info = lora::g_last_info;

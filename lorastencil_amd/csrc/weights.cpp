@@ -366,6 +366,28 @@ int lora_factorize_7x7(const double *params, double *u, double *v, double *resid
                                residual_max);
 }
 
+// host-side bf16 conversion (round-to-nearest-even; NaN stays a quiet NaN)
+static uint16_t f32_to_bf16_bits(float f) {
+    uint32_t u;
+    std::memcpy(&u, &f, 4);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t) ((u >> 16) | 0x0040u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t) (u >> 16);
+}
+
+void lora_f64_to_bf16(const double *src, uint16_t *dst, size_t count) {
+    for (size_t i = 0; i < count; ++i) dst[i] = f32_to_bf16_bits((float) src[i]);
+}
+
+void lora_bf16_to_f64(const uint16_t *src, double *dst, size_t count) {
+    for (size_t i = 0; i < count; ++i) {
+        const uint32_t u = (uint32_t) src[i] << 16;
+        float f;
+        std::memcpy(&f, &u, 4);
+        dst[i] = f;
+    }
+}
+
 // glibc TYPE_3 generator: x[i] = x[i-3] + x[i-31] (mod 2^32), output x[i] >> 1; the 34-entry
 // state is primed with a Lehmer sequence and the first 310 outputs are thrown away.
 void lora_rng_seed(lora_rng *g, unsigned seed) {
