@@ -213,6 +213,13 @@ int lora_factorize_7x7(const double *params, double *u, double *v, double *resid
  * spectral norm sigma[r].  The MFMA variant uses it for taps the pyramid factoriser cannot take. */
 int lora_svd_7x7(const double *weights, double *u, double *v, double *sigma);
 
+/* Exact rank-1 test of 3x3x3 taps as the bf16 sweeps see them (cast to fp32): returns 1 and fills
+ * cba9 = {c[0..2] (x), b[0..2] (y), a[0..2] (z)} when fl(fl(a[dz] * b[dy]) * c[dx]) == w[dz][dy][dx] for all 27
+ * taps, else 0.  Every box3d1r the reference can express passes (gpu_box_3d1r honours params[0..2] only,
+ * 3d/gpu_box.cu:143-226); bf16 plans then evaluate the sweep as x-, y- and z-passes (plan option "separable",
+ * default on; the evaluation order is documented in kernels_3d_bf16.hip and restated by the oracle). */
+int lora_separable_3x3x3(const double *weights27, float *cba9);
+
 /* bf16 <-> double on the host (round-to-nearest-even; bf16 values are bit patterns in uint16_t). */
 void lora_f64_to_bf16(const double *src, uint16_t *dst, size_t count);
 void lora_bf16_to_f64(const uint16_t *src, double *dst, size_t count);

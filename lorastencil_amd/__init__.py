@@ -30,6 +30,7 @@ from .ops import (  # noqa: F401
     padded_shape,
     reference_input,
     run_host,
+    separable_3x3x3,
     svd_7x7,
     to_bf16,
 )

@@ -98,6 +98,7 @@ SIGNATURES = {
     "lora_effective_weights": (ctypes.c_int, [ctypes.c_int, _dp, _dp]),
     "lora_factorize_7x7": (ctypes.c_int, [_dp, _dp, _dp, _dp]),
     "lora_svd_7x7": (ctypes.c_int, [_dp, _dp, _dp, _dp]),
+    "lora_separable_3x3x3": (ctypes.c_int, [_dp, ctypes.POINTER(ctypes.c_float)]),
     "lora_rng_seed": (None, [ctypes.POINTER(Rng), ctypes.c_uint]),
     "lora_rng_next": (ctypes.c_int, [ctypes.POINTER(Rng)]),
     "lora_fill_rand": (None, [_dp, ctypes.c_size_t, ctypes.c_int, ctypes.POINTER(Rng)]),

@@ -216,6 +216,11 @@ void plan_refresh(Plan &p) {
             if ((dz != 1) + (dy != 1) + (dx != 1) > 1) star = false;
         }
         p.tapset = star ? TAPS3D_STAR : TAPS3D_BOX;
+        if (!star && p.dtype == LORA_BF16 && p.separable != 0) {
+            float w32[27];
+            for (int k = 0; k < 27; ++k) w32[k] = (float) p.w[k];
+            if (separable_27(w32, p.sep)) p.tapset = TAPS3D_SEP;
+        }
         p.kernel_name = (p.dtype == LORA_BF16) ? kernel_name_3d_bf16(p) : (p.generic ? kernel_name_generic(p) : kernel_name_3d(p));
     } else {
         p.tapset = 0;
@@ -430,6 +435,11 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "lowrank_valu")) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.lowrank_valu = value;
+    } else if (!std::strcmp(key, "separable")) {
+        if (value < -1 || value > 1) return LORA_EINVAL;
+        p.separable = value;
+    } else if (!std::strcmp(key, "ablate")) {
+        p.ablate = value & 3;
     } else if (!std::strcmp(key, "lds_dma")) {
         p.lds_dma = value ? 1 : 0;
     } else if (!std::strcmp(key, "cols_per_lane")) {
@@ -473,6 +483,8 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.lowrank_valu;
     else if (!std::strcmp(key, "lds_dma"))
         *value = p.lds_dma;
+    else if (!std::strcmp(key, "separable"))
+        *value = p.separable;
     else if (!std::strcmp(key, "cols_per_lane"))
         *value = p.cols_per_lane;
     else if (!std::strcmp(key, "fused_rows"))

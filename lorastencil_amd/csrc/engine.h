@@ -17,10 +17,11 @@ int default_params(int shape, double *params);
 int effective_weights(int shape, const double *params, double *weights);
 int factorize_7x7(const double *params, double u[4][7], double v[4][7], double *residual_max);
 int svd_7x7(const double *W, double u[7][7], double v[7][7], double sigma[7]);
+int separable_27(const float *w27, float *cba9);  // exact rank-1 test of fp32 3x3x3 taps; cba = c(x), b(y), a(z)
 
 // ---- tap sets: which of the 49 / 27 taps a kernel instantiation evaluates --------------------
 enum TapSet2D { TAPS2D_DIAMOND = 0, TAPS2D_STAR = 1, TAPS2D_BOX = 2 };
-enum TapSet3D { TAPS3D_STAR = 0, TAPS3D_BOX = 1 };
+enum TapSet3D { TAPS3D_STAR = 0, TAPS3D_BOX = 1, TAPS3D_SEP = 2 };  // SEP: w = a (x) b (x) c exactly (bf16 path)
 
 struct Taps9 {
     double w[9];
@@ -57,6 +58,9 @@ struct Plan {
     int fused_rows_req = 0;   // 0 = auto, else 6 / 8 / 10
     int fused_rows = 8;       // 2D fused: intermediate rows per wave (tile = 4x this - 6 output rows), resolved
     int cols_per_lane = 4;    // 3D bf16: 4 (512-byte row pieces per wave) or 8 (1 KiB)
+    int separable = -1;       // 3D bf16: evaluate exactly-separable taps as x/y/z passes: -1 auto (= on), 0 off
+    float sep[9] = {0};       // resolved factors c(x), b(y), a(z) when tapset == TAPS3D_SEP
+    int ablate = 0;           // diagnostics only (3D bf16): 1 = skip stores, 2 = skip plane loads
     int lds_dma = 0;          // 3D bf16: global_load_lds ring, two planes ahead (hand-counted vmcnt)
     int persistent = 0;       // 2D fused: persistent workgroups with register prefetch of the next tile
     int z_chunk = 16;         // 3D: output planes streamed per workgroup

@@ -6,6 +6,15 @@
 // (dz, dy, dx; 3d/main.cu:33-68) against fp32 taps, and rounds ONCE to bf16 (round-to-nearest-even) on store.
 // The same order and roundings make the result bit-identical to the oracle.
 //
+// Separable taps (TAPS3D_SEP): when the fp32 taps factor EXACTLY as w[dz][dy][dx] = a[dz] * b[dy] * c[dx]
+// (weights.cpp separable_27; every box3d1r the reference's API can express does, because gpu_box_3d1r honours only
+// params[0..2] = c, 3d/gpu_box.cu:143-226), the sweep is evaluated as the rank-1 product it is -- the 3D form of
+// the paper's low-rank idea: T = x-pass (3 FMAs per staged element), U = y-pass of T, out = z-pass of U; 10.5
+// instead of 27 multiply-adds per point.  The 27-tap form spends 0.275 ms of a 0.45 ms 768^3 sweep in the vector
+// pipe with loads and stores removed (option `ablate`), so the tap count is what bounds it.  The order is part of
+// the contract: T = fma(c2,x+,fma(c1,x0,c0*x-)), U and out likewise over y and z, all fp32, one rounding to bf16;
+// oracle_step_3d_bf16_sep restates exactly that.
+//
 // Why not bf16 MFMA: the in-plane product (H X) V on v_mfma_f32_16x16x32_bf16 needs its
 // first-stage result as a bf16 operand of the second stage -- an extra rounding of the intermediate that the
 // "fp32 accumulate" contract does not have -- and at 4 algorithmic bytes per point the sweep is HBM-bound on the
@@ -70,7 +79,67 @@ struct Args3Dh {
     int z_begin, z_end;
     int zc;
     int tiles_x, tiles_y;
+    int ablate;  // timing-only diagnostics: 1 = no stores, 2 = no plane loads (results are then wrong)
 };
+
+// One staged row `j` of plane phase PHASE applied to the rotating output-plane accumulators of a lane.
+// pr[k] = window elements (3+k, 4+k) as an fp32 pair; NP column pairs per lane.  Called from fully unrolled loops,
+// so j and every register index is a compile-time constant after inlining.
+template <int TAPSET, int RY, int NP, int PHASE>
+__device__ __forceinline__ void accumulate_row(f2 (&acc)[3][RY][NP], f2 (&u)[RY][NP], const f2 *pr, int j,
+                                               const Taps27f &W) {
+    if constexpr (TAPSET == TAPS3D_SEP) {
+        // W.w[0..2] = c (x), [3..5] = b (y), [6..8] = a (z)
+        f2 t[NP];
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            t[c] = (f2){W.w[0], W.w[0]} * pr[2 * c];
+            t[c] = __builtin_elementwise_fma((f2){W.w[1], W.w[1]}, pr[2 * c + 1], t[c]);
+            t[c] = __builtin_elementwise_fma((f2){W.w[2], W.w[2]}, pr[2 * c + 2], t[c]);
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int r = j - dy;
+            if (r >= 0 && r < RY) {
+                const f2 b2 = (f2){W.w[3 + dy], W.w[3 + dy]};
+#pragma unroll
+                for (int c = 0; c < NP; ++c) u[r][c] = dy == 0 ? b2 * t[c] : __builtin_elementwise_fma(b2, t[c], u[r][c]);
+            }
+        }
+        if (j >= 2) {  // U row j-2 is complete: z-pass into the three output planes it touches
+            const int r = j - 2;
+#pragma unroll
+            for (int dz = 0; dz < 3; ++dz) {
+                const int s = (PHASE - dz + 3) % 3;
+                const f2 a2 = (f2){W.w[6 + dz], W.w[6 + dz]};
+#pragma unroll
+                for (int c = 0; c < NP; ++c)
+                    acc[s][r][c] = dz == 0 ? a2 * u[r][c] : __builtin_elementwise_fma(a2, u[r][c], acc[s][r][c]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+            const int s = (PHASE - dz + 3) % 3;
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                const int dy = j - r;
+                if (dy >= 0 && dy < 3) {
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        if (tap_on3<TAPSET>(dz, dy, dx)) {
+                            const float wt = W.w[dz * 9 + dy * 3 + dx];
+                            const f2 wt2 = (f2){wt, wt};
+#pragma unroll
+                            for (int c = 0; c < NP; ++c)
+                                acc[s][r][c] = __builtin_elementwise_fma(wt2, pr[2 * c + dx], acc[s][r][c]);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
 
 template <int TAPSET, int RY, int CPL>
 __global__ __launch_bounds__(256, (CPL == 4 ? 4 : 3)) void stencil3d_bf16_kernel(const Args3Dh a, const Taps27f W) {
@@ -146,8 +215,9 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 4 : 3)) void stencil3d_bf16_kernel
     auto consume = [&](int p, auto phase_tag) {
         constexpr int PHASE = decltype(phase_tag)::value;
         const bool more = p + 1 < nplanes;
-        if (more) load_plane(p + 1);
+        if (more && !(a.ablate & 2)) load_plane(p + 1);
         const u16 *strip = reinterpret_cast<const u16 *>(&tile[p & 1][0]) + strip_off;
+        f2 u[RY][CPL / 2];  // y-pass partial sums of this plane (separable form only)
 #pragma unroll
         for (int j = 0; j < RY + 2; ++j) {
             // d[i] holds window elements (2i, 2i+1).  A tap dx of column pair c needs elements (3+2c+dx, 4+2c+dx):
@@ -162,26 +232,7 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 4 : 3)) void stencil3d_bf16_kernel
             f2 pr[CPL + 1];  // pr[k] = elements (3+k, 4+k)
 #pragma unroll
             for (int k = 0; k < CPL + 1; ++k) pr[k] = (f2){win_elem(d, 3 + k), win_elem(d, 4 + k)};
-#pragma unroll
-            for (int dz = 0; dz < 3; ++dz) {
-                const int s = (PHASE - dz + 3) % 3;
-#pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    const int dy = j - r;
-                    if (dy >= 0 && dy < 3) {
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            if (tap_on3<TAPSET>(dz, dy, dx)) {
-                                const float wt = W.w[dz * 9 + dy * 3 + dx];
-                                const f2 wt2 = (f2){wt, wt};
-#pragma unroll
-                                for (int c = 0; c < CPL / 2; ++c)
-                                    acc[s][r][c] = __builtin_elementwise_fma(wt2, pr[2 * c + dx], acc[s][r][c]);
-                            }
-                        }
-                    }
-                }
-            }
+            accumulate_row<TAPSET, RY, CPL / 2, PHASE>(acc, u, pr, j, W);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -194,7 +245,7 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 4 : 3)) void stencil3d_bf16_kernel
         {
             constexpr int s = (PHASE - 2 + 3) % 3;
             const int o = p - 2;
-            if (o >= 0 && o < zc && col_ok) {
+            if (o >= 0 && o < zc && col_ok && !(a.ablate & 1)) {
                 u16 *dst = out_col + (long) (k0 + o + 1) * a.plane;
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
@@ -209,10 +260,12 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 4 : 3)) void stencil3d_bf16_kernel
                     }
                 }
             }
+            if constexpr (TAPSET != TAPS3D_SEP) {  // the separable form assigns on its first z tap
 #pragma unroll
-            for (int r = 0; r < RY; ++r)
+                for (int r = 0; r < RY; ++r)
 #pragma unroll
-                for (int c = 0; c < CPL / 2; ++c) acc[s][r][c] = (f2){0.0f, 0.0f};
+                    for (int c = 0; c < CPL / 2; ++c) acc[s][r][c] = (f2){0.0f, 0.0f};
+            }
         }
         if (more) write_plane((p + 1) & 1);
         __syncthreads();
@@ -318,6 +371,7 @@ __global__ __launch_bounds__(256, 4) void stencil3d_bf16_ring_kernel(const Args3
         asm volatile("" ::: "memory");
         if (p + 2 < nplanes) issue_plane(p + 2, (PHASE + 2) % 3);  // slot of plane p-1: every wave is done with it
         const u16 *strip = reinterpret_cast<const u16 *>(&ring[PHASE][0]) + strip_off;
+        f2 u[RY][2];
 #pragma unroll
         for (int j = 0; j < RY + 2; ++j) {
             unsigned d[6];
@@ -333,26 +387,7 @@ __global__ __launch_bounds__(256, 4) void stencil3d_bf16_ring_kernel(const Args3
             pr[2] = (f2){bf16_hi(d[2]), bf16_lo(d[3])};
             pr[3] = (f2){bf16_lo(d[3]), bf16_hi(d[3])};
             pr[4] = (f2){bf16_hi(d[3]), bf16_lo(d[4])};
-#pragma unroll
-            for (int dz = 0; dz < 3; ++dz) {
-                const int s = (PHASE - dz + 3) % 3;
-#pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    const int dy = j - r;
-                    if (dy >= 0 && dy < 3) {
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            if (tap_on3<TAPSET>(dz, dy, dx)) {
-                                const float wt = W.w[dz * 9 + dy * 3 + dx];
-                                const f2 wt2 = (f2){wt, wt};
-#pragma unroll
-                                for (int c = 0; c < 2; ++c)
-                                    acc[s][r][c] = __builtin_elementwise_fma(wt2, pr[2 * c + dx], acc[s][r][c]);
-                            }
-                        }
-                    }
-                }
-            }
+            accumulate_row<TAPSET, RY, 2, PHASE>(acc, u, pr, j, W);
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll
@@ -372,10 +407,12 @@ __global__ __launch_bounds__(256, 4) void stencil3d_bf16_ring_kernel(const Args3
                 v.y = pack_bf16(acc[s][r][1].x, acc[s][r][1].y);
                 __builtin_amdgcn_raw_buffer_store_b64(v, dst, store_off[r], 0, 0);
             }
+            if constexpr (TAPSET != TAPS3D_SEP) {
 #pragma unroll
-            for (int r = 0; r < RY; ++r)
+                for (int r = 0; r < RY; ++r)
 #pragma unroll
-                for (int c = 0; c < 2; ++c) acc[s][r][c] = (f2){0.0f, 0.0f};
+                    for (int c = 0; c < 2; ++c) acc[s][r][c] = (f2){0.0f, 0.0f};
+            }
         }
     };
 
@@ -403,12 +440,15 @@ hipError_t launch_bf16(const Plan &p, const void *in, void *out, int begin, int 
     a.zc = p.z_chunk < 1 ? 1 : p.z_chunk;
     a.tiles_x = (a.n + kTileW - 1) / kTileW;
     a.tiles_y = (a.m + TY - 1) / TY;
+    a.ablate = p.ablate;
     const long chunks = ((long) end - begin + a.zc - 1) / a.zc;
     const long nblocks = chunks * a.tiles_x * a.tiles_y;
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
     Taps27f w;
     for (int k = 0; k < 27; ++k) w.w[k] = (float) p.w[k];
+    if (TAPSET == TAPS3D_SEP)
+        for (int k = 0; k < 9; ++k) w.w[k] = p.sep[k];
     if (a.plane * 2 >= (1L << 32)) return hipErrorInvalidValue;  // per-plane buffer descriptors: 32-bit offsets
     if (CPL == 4 && p.lds_dma)
         hipLaunchKernelGGL((stencil3d_bf16_ring_kernel<TAPSET, RY>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
@@ -421,6 +461,8 @@ hipError_t launch_bf16(const Plan &p, const void *in, void *out, int begin, int 
 
 hipError_t launch_3d_bf16(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s) {
     const bool wide = p.cols_per_lane == 8 && !p.lds_dma;
+    if (p.tapset == TAPS3D_SEP)
+        return wide ? launch_bf16<TAPS3D_SEP, 8>(p, in, out, begin, end, s) : launch_bf16<TAPS3D_SEP, 4>(p, in, out, begin, end, s);
     if (p.tapset == TAPS3D_STAR)
         return wide ? launch_bf16<TAPS3D_STAR, 8>(p, in, out, begin, end, s) : launch_bf16<TAPS3D_STAR, 4>(p, in, out, begin, end, s);
     return wide ? launch_bf16<TAPS3D_BOX, 8>(p, in, out, begin, end, s) : launch_bf16<TAPS3D_BOX, 4>(p, in, out, begin, end, s);

@@ -241,6 +241,34 @@ int svd_7x7(const double *W, double u[7][7], double v[7][7], double sigma[7]) {
     return LORA_OK;
 }
 
+// Exact rank-1 test of a 3 x 3 x 3 fp32 tap tensor: w[dz][dy][dx] == (a[dz] * b[dy]) * c[dx] with every product
+// rounded to fp32.  The factors are read off the three axes through the centre tap (c as stored, a and b divided
+// by the centre), so a tensor that passes is evaluated with exactly these numbers (kernels_3d_bf16.hip, TAPS3D_SEP).
+// cba = {c[0..2], b[0..2], a[0..2]}.  Returns 1 when the test holds.
+int separable_27(const float *w, float *cba) {
+    const float centre = w[13];
+    if (!(centre != 0.0f) || !std::isfinite(centre)) return 0;
+    float c[3], b[3], a[3];
+    for (int i = 0; i < 3; ++i) {
+        c[i] = w[9 + 3 + i];
+        b[i] = w[9 + 3 * i + 1] / centre;
+        a[i] = w[9 * i + 3 + 1] / centre;
+    }
+    for (int dz = 0; dz < 3; ++dz)
+        for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) {
+                const float ab = a[dz] * b[dy];
+                const float abc = ab * c[dx];
+                if (!(abc == w[dz * 9 + dy * 3 + dx])) return 0;
+            }
+    for (int i = 0; i < 3; ++i) {
+        cba[i] = c[i];
+        cba[3 + i] = b[i];
+        cba[6 + i] = a[i];
+    }
+    return 1;
+}
+
 int effective_weights(int shape, const double *params, double *w) {
     switch (shape) {
         case LORA_1D1R:
@@ -353,6 +381,13 @@ int lora_effective_weights(int shape, const double *params, double *weights) {
         params = tmp;
     }
     return lora::effective_weights(shape, params, weights);
+}
+
+int lora_separable_3x3x3(const double *weights27, float *cba9) {
+    if (!weights27 || !cba9) return LORA_EINVAL;
+    float w[27];
+    for (int k = 0; k < 27; ++k) w[k] = (float) weights27[k];
+    return lora::separable_27(w, cba9);
 }
 
 int lora_svd_7x7(const double *weights, double *u, double *v, double *sigma) {

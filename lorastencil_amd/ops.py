@@ -128,6 +128,19 @@ def svd_7x7(weights):
     return u, v, sig
 
 
+def separable_3x3x3(weights):
+    """Exact rank-1 test of 27 taps in fp32 (what bf16 plans evaluate): returns (c, b, a) float32 factors along
+    x, y, z when w[dz,dy,dx] == (a[dz] * b[dy]) * c[dx] holds exactly, else None."""
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    if weights.size != 27:
+        raise ValueError("weights must hold 27 values")
+    cba = np.zeros(9, dtype=np.float32)
+    rc = _lib.lib().lora_separable_3x3x3(_p(weights), cba.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    if rc < 0:
+        check(rc, "lora_separable_3x3x3")
+    return (cba[0:3].copy(), cba[3:6].copy(), cba[6:9].copy()) if rc == 1 else None
+
+
 class GlibcRand:
     """glibc ``rand()`` stream; seed 1 is what the reference's un-seeded harness draws from."""
 

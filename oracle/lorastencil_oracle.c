@@ -417,8 +417,70 @@ void oracle_step_3d_bf16(const uint16_t *in, uint16_t *out, const float *w, int 
     }
 }
 
+/* Exact rank-1 test of fp32 3x3x3 taps (the engine's lora_separable_3x3x3 restated): factors read off the three
+ * axes through the centre tap; holds iff fl(fl(a[dz] * b[dy]) * c[dx]) == w[dz][dy][dx] for all 27 taps. */
+int oracle_separable_27(const float *w, float *c, float *b, float *a) {
+    const float centre = w[13];
+    if (!(centre != 0.0f) || isinf(centre)) return 0;
+    for (int i = 0; i < 3; i++) {
+        c[i] = w[12 + i];
+        b[i] = w[9 + 3 * i + 1] / centre;
+        a[i] = w[9 * i + 4] / centre;
+    }
+    for (int k = 0; k < 27; k++) {
+        const float ab = a[k / 9] * b[(k / 3) % 3];
+        const float abc = ab * c[k % 3];
+        if (!(abc == w[k])) return 0;
+    }
+    return 1;
+}
+
+/* One bf16 sweep of separable taps in the engine's documented order (kernels_3d_bf16.hip, TAPS3D_SEP):
+ *   T = fma(c2, x[+1], fma(c1, x[0], c0 * x[-1]))      along x, fp32
+ *   U = fma(b2, T[+1], fma(b1, T[0], b0 * T[-1]))      along y
+ *   out = bf16(fma(a2, U[+1], fma(a1, U[0], a0 * U[-1])))   along z, one rounding to bf16
+ * (built with -ffp-contract=off, so the plain products stay separate roundings). */
+void oracle_step_3d_bf16_sep(const uint16_t *in, uint16_t *out, const float *c, const float *b, const float *a,
+                             int heights, int rows, int cols, int threads) {
+    const int nt = pick_threads(threads);
+    (void) nt;
+    const ptrdiff_t plane = (ptrdiff_t) rows * cols;
+#pragma omp parallel for num_threads(nt) schedule(static) collapse(2) if (nt > 1)
+    for (int h = 1; h < heights - 1; h++) {
+        for (int row = 2; row < rows - 2; row++) {
+            for (int col = 4; col < cols - 4; col++) {
+                float U[3];
+                for (int dz = 0; dz < 3; dz++) {
+                    float T[3];
+                    for (int dy = 0; dy < 3; dy++) {
+                        const uint16_t *x = in + (h + dz - 1) * plane + (ptrdiff_t) (row + dy - 1) * cols + col;
+                        float t = c[0] * oracle_bf16_to_f32(x[-1]);
+                        t = fmaf(c[1], oracle_bf16_to_f32(x[0]), t);
+                        t = fmaf(c[2], oracle_bf16_to_f32(x[1]), t);
+                        T[dy] = t;
+                    }
+                    float u = b[0] * T[0];
+                    u = fmaf(b[1], T[1], u);
+                    u = fmaf(b[2], T[2], u);
+                    U[dz] = u;
+                }
+                float o = a[0] * U[0];
+                o = fmaf(a[1], U[1], o);
+                o = fmaf(a[2], U[2], o);
+                out[h * plane + (ptrdiff_t) row * cols + col] = oracle_f32_to_bf16(o);
+            }
+        }
+    }
+}
+
 int oracle_run_bf16(int shape, const uint16_t *in, uint16_t *out, const double *w27, int times, const int *dims,
                     int threads) {
+    return oracle_run_bf16_mode(shape, in, out, w27, times, dims, threads, 0);
+}
+
+/* separable != 0: the engine's default -- exactly separable taps go through oracle_step_3d_bf16_sep. */
+int oracle_run_bf16_mode(int shape, const uint16_t *in, uint16_t *out, const double *w27, int times, const int *dims,
+                         int threads, int separable) {
     if (shape_dim(shape) != 3 || times < 0) return -1;
     const size_t count = oracle_padded_count(shape, dims);
     float w[27];
@@ -432,8 +494,14 @@ int oracle_run_bf16(int shape, const uint16_t *in, uint16_t *out, const double *
         return -1;
     }
     memcpy(buf[0], in, count * sizeof(uint16_t));
-    for (int i = 0; i < times; i++)
-        oracle_step_3d_bf16(buf[i % 2], buf[(i + 1) % 2], w, dims[0] + 2, dims[1] + 4, dims[2] + 8, threads);
+    float c[3], b[3], a[3];
+    const int sep = separable && oracle_separable_27(w, c, b, a);
+    for (int i = 0; i < times; i++) {
+        if (sep)
+            oracle_step_3d_bf16_sep(buf[i % 2], buf[(i + 1) % 2], c, b, a, dims[0] + 2, dims[1] + 4, dims[2] + 8, threads);
+        else
+            oracle_step_3d_bf16(buf[i % 2], buf[(i + 1) % 2], w, dims[0] + 2, dims[1] + 4, dims[2] + 8, threads);
+    }
     memcpy(out, buf[times % 2], count * sizeof(uint16_t));
     free(buf[0]);
     free(buf[1]);

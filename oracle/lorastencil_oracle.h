@@ -111,6 +111,14 @@ void oracle_step_3d_bf16(const uint16_t *in, uint16_t *out, const float *w27, in
                          int threads);
 int oracle_run_bf16(int shape, const uint16_t *in, uint16_t *out, const double *w27, int times, const int *dims,
                     int threads);
+/* Separable taps (w = a (x) b (x) c exactly in fp32; every box3d1r of the reference's API): the engine's bf16 plans
+ * evaluate x-, y-, z-passes; the order is restated in oracle_step_3d_bf16_sep.  oracle_run_bf16_mode(..., 1) is the
+ * engine's default behaviour (separable form when the exact test holds), (..., 0) the 27-tap order. */
+int oracle_separable_27(const float *w27, float *c, float *b, float *a);
+void oracle_step_3d_bf16_sep(const uint16_t *in, uint16_t *out, const float *c, const float *b, const float *a,
+                             int heights, int rows, int cols, int threads);
+int oracle_run_bf16_mode(int shape, const uint16_t *in, uint16_t *out, const double *w27, int times, const int *dims,
+                         int threads, int separable);
 
 /* Padded element count of a shape/dims (1D n+8; 2D (m+8)(n+8); 3D (h+2)(m+4)(n+8)). */
 size_t oracle_padded_count(int shape, const int *dims);

@@ -80,6 +80,13 @@ def lib() -> ctypes.CDLL:
                                           ctypes.c_int, ctypes.c_int]
         L.oracle_run_bf16.argtypes = [ctypes.c_int, _u16, _u16, _dp, ctypes.c_int, _ip, ctypes.c_int]
         L.oracle_run_bf16.restype = ctypes.c_int
+        L.oracle_run_bf16_mode.argtypes = [ctypes.c_int, _u16, _u16, _dp, ctypes.c_int, _ip, ctypes.c_int, ctypes.c_int]
+        L.oracle_run_bf16_mode.restype = ctypes.c_int
+        _fp = ctypes.POINTER(ctypes.c_float)
+        L.oracle_separable_27.argtypes = [_fp, _fp, _fp, _fp]
+        L.oracle_separable_27.restype = ctypes.c_int
+        L.oracle_step_3d_bf16_sep.argtypes = [_u16, _u16, _fp, _fp, _fp, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_int]
         _lib = L
     return _lib
 
@@ -228,8 +235,19 @@ def from_bf16(b: np.ndarray) -> np.ndarray:
     return (np.ascontiguousarray(b, dtype=np.uint16).astype(np.uint32) << 16).view(np.float32).astype(np.float64)
 
 
-def run_bf16(shape, a_bits: np.ndarray, times: int, weights=None, threads: int = 1) -> np.ndarray:
-    """The 3D operator on bf16 bit patterns with the reference's driver semantics."""
+def separable_27(weights):
+    """Exact fp32 rank-1 test of 27 taps: (c, b, a) float32 factors along x, y, z, or None."""
+    w = np.ascontiguousarray(weights, dtype=np.float64).astype(np.float32).ravel()
+    assert w.size == 27
+    c, b, a = (np.zeros(3, dtype=np.float32) for _ in range(3))
+    fp = ctypes.POINTER(ctypes.c_float)
+    ok = lib().oracle_separable_27(w.ctypes.data_as(fp), c.ctypes.data_as(fp), b.ctypes.data_as(fp), a.ctypes.data_as(fp))
+    return (c, b, a) if ok else None
+
+
+def run_bf16(shape, a_bits: np.ndarray, times: int, weights=None, threads: int = 1, separable: bool = True) -> np.ndarray:
+    """The 3D operator on bf16 bit patterns with the reference's driver semantics.  ``separable`` (the engine's
+    default) evaluates exactly separable taps as x/y/z passes; False is the 27-tap order."""
     sid = shape_id(shape)
     a_bits = np.ascontiguousarray(a_bits, dtype=np.uint16)
     w = effective_weights(sid) if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
@@ -237,9 +255,10 @@ def run_bf16(shape, a_bits: np.ndarray, times: int, weights=None, threads: int =
     dims = (ctypes.c_int * 3)(*[a_bits.shape[i] - 2 * h[i] for i in range(3)])
     out = np.zeros_like(a_bits)
     u16 = ctypes.POINTER(ctypes.c_uint16)
-    rc = lib().oracle_run_bf16(sid, a_bits.ctypes.data_as(u16), out.ctypes.data_as(u16), _p(w), times, dims, threads)
+    rc = lib().oracle_run_bf16_mode(sid, a_bits.ctypes.data_as(u16), out.ctypes.data_as(u16), _p(w), times, dims,
+                                    threads, 1 if separable else 0)
     if rc != 0:
-        raise ValueError("oracle_run_bf16 failed")
+        raise ValueError("oracle_run_bf16_mode failed")
     return out
 
 

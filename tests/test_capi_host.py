@@ -112,6 +112,39 @@ def test_glibc_rand_fill_matches_oracle_and_golden(L):
         assert np.array_equal(L.reference_input(shape, tuple(g["dims"])), g["input"])
 
 
+def test_separable_tap_test_matches_oracle(L):
+    """bf16 plans evaluate exactly separable 3x3x3 taps as x/y/z passes; engine and oracle must take the same
+    decision and read off the same fp32 factors (a different decision would change the summation order)."""
+    rng = np.random.default_rng(29)
+    cases = [O.effective_weights("box3d1r"), O.effective_weights("box3d1r") / 36.0, O.effective_weights("star3d1r"),
+             np.zeros(27), np.einsum("k,i,j->kij", [1, 2, 1], [0.5, 1, 0.5], [3, 5, 7.0]).ravel()]
+    for _ in range(50):  # every box3d1r of the reference's API: w[dz][dy][dx] = params[dx]
+        prm = np.zeros(27)
+        prm[:3] = rng.standard_normal(3)
+        cases.append(O.effective_weights("box3d1r", prm))
+    for _ in range(50):  # rank-1 in fp64; rarely exactly so after the fp32 cast
+        a, b, c = rng.standard_normal((3, 3))
+        cases.append(np.einsum("k,i,j->kij", a, b, c).ravel())
+    cases.append(rng.standard_normal(27))
+    n_sep = 0
+    for w in cases:
+        e, o = L.separable_3x3x3(w), O.separable_27(w)
+        assert (e is None) == (o is None)
+        if e is not None:
+            n_sep += 1
+            for fe, fo in zip(e, o):
+                assert fe.dtype == np.float32 and np.array_equal(fe, fo)
+            c, b, a = (f.astype(np.float32) for f in e)
+            rebuilt = ((a[:, None, None] * b[None, :, None]).astype(np.float32) * c[None, None, :]).astype(np.float32)
+            assert np.array_equal(rebuilt.ravel(), np.asarray(w, dtype=np.float64).astype(np.float32))
+    assert n_sep >= 53  # the two reference tables, the anisotropic case and all 50 params[0..2] draws
+    assert L.separable_3x3x3(O.effective_weights("star3d1r")) is None
+    plan = L.Plan("box3d1r", (8, 8, 16), dtype="bf16")
+    assert plan.get_option("tapset") == 2 and plan.get_option("separable") == -1
+    assert plan.set_option("separable", 0).get_option("tapset") == 1
+    assert L.Plan("box3d1r", (8, 8, 16)).get_option("tapset") == 1  # fp64 keeps the 27-tap order (HBM-bound)
+
+
 def test_bf16_conversion_matches_oracle(L):
     rng = np.random.default_rng(3)
     x = np.concatenate([rng.standard_normal(20000) * 10.0 ** rng.uniform(-35, 35, 20000),

@@ -395,6 +395,46 @@ def test_bf16_sweeps_match_oracle_bit_exact(L, O, shape, dims):
         assert np.array_equal(plan_run_bf16(L, shape, bits, t, options={"cols_per_lane": 8}), O.run_bf16(shape, bits, t))
 
 
+def test_bf16_separable_and_tap_order_forms(L, O):
+    """Exactly separable taps (every box3d1r of the reference's API) run as x/y/z passes -- a different fp32
+    summation order, restated by oracle_step_3d_bf16_sep; option separable=0 keeps the 27-tap order.  Both must
+    equal their oracle bit for bit, make the same separable/not decision as the oracle, and stay within bf16
+    precision of each other and of the fp64 result."""
+    rng = np.random.default_rng(23)
+    shape, dims = "box3d1r", (10, 19, 136)
+    bits = O.to_bf16(rng.standard_normal(O.padded_shape(shape, dims)))
+    ref_w = O.effective_weights(shape) / 36.0
+    aniso = np.einsum("k,i,j->kij", [0.25, 0.5, 0.125], [1.0, 2.0, 1.0], [0.0625, 0.125, 0.03125]).ravel()
+    a, b, c = rng.standard_normal((3, 3))
+    inexact = np.einsum("k,i,j->kij", a, b, c).ravel() / 8.0       # rank-1 in fp64, not exactly so in fp32
+    assert O.separable_27(ref_w) is not None and O.separable_27(aniso) is not None
+    for w, name in ((ref_w, "reference"), (aniso, "anisotropic"), (inexact, "inexact")):
+        sep = O.separable_27(w) is not None
+        eng = L.separable_3x3x3(w)
+        assert (eng is not None) == sep, name
+        plan = L.Plan(shape, dims, dtype="bf16").set_weights(w)
+        assert plan.get_option("tapset") == (2 if sep else 1), name
+        plan.close()
+        for t in (1, 6):
+            exp_sep = O.run_bf16(shape, bits, t, weights=w, separable=True)
+            exp_tap = O.run_bf16(shape, bits, t, weights=w, separable=False)
+            for opts in ({}, {"lds_dma": 1}, {"cols_per_lane": 8}, {"z_chunk": 3}):
+                assert np.array_equal(plan_run_bf16(L, shape, bits, t, weights=w, options=opts), exp_sep), (name, t, opts)
+                off = dict(opts, separable=0)
+                assert np.array_equal(plan_run_bf16(L, shape, bits, t, weights=w, options=off), exp_tap), (name, t, off)
+            if not sep:
+                assert np.array_equal(exp_sep, exp_tap)
+        # one sweep of either order is the correctly rounded fp64 sum up to fp32 accumulation error: they differ
+        # from the exact result by at most one bf16 ulp (2^-8 relative) plus ~27 fp32 roundings of the |taps| sum
+        exact = O.run(shape, O.from_bf16(bits), 1, weights=w)
+        scale = O.run(shape, np.abs(O.from_bf16(bits)), 1, weights=np.abs(w))
+        for form in (True, False):
+            got = O.from_bf16(plan_run_bf16(L, shape, bits, 1, weights=w, options={"separable": int(form)}))
+            err = np.abs(O.interior(shape, got) - O.interior(shape, exact))
+            bound = 2.0 ** -8 * np.abs(O.interior(shape, exact)) + 30 * 2.0 ** -24 * O.interior(shape, scale)
+            assert (err <= bound).all(), (name, form)
+
+
 def test_bf16_host_operator_and_random_taps(L, O):
     rng = np.random.default_rng(11)
     shape, dims = "box3d1r", (6, 10, 64)

@@ -76,8 +76,14 @@ class OracleStepperBf16:
         s = np.ascontiguousarray(src.view(torch.int16).numpy().view(np.uint16)[begin:end + 2])
         out = np.zeros_like(s)
         u16 = ctypes.POINTER(ctypes.c_uint16)
-        O.lib().oracle_step_3d_bf16(s.ctypes.data_as(u16), out.ctypes.data_as(u16),
-                                    self.w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), *s.shape, 1)
+        fp = ctypes.POINTER(ctypes.c_float)
+        sep = O.separable_27(self.w)  # the engine's default: exactly separable taps run as x/y/z passes
+        if sep is not None:
+            O.lib().oracle_step_3d_bf16_sep(s.ctypes.data_as(u16), out.ctypes.data_as(u16),
+                                            *(f.ctypes.data_as(fp) for f in sep), *s.shape, 1)
+        else:
+            O.lib().oracle_step_3d_bf16(s.ctypes.data_as(u16), out.ctypes.data_as(u16), self.w.ctypes.data_as(fp),
+                                        *s.shape, 1)
         d = dst.view(torch.int16).numpy().view(np.uint16)[begin:end + 2]
         d[1:-1, 2:-2, 4:-4] = out[1:-1, 2:-2, 4:-4]
 
