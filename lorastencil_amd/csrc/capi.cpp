@@ -221,7 +221,13 @@ void plan_refresh(Plan &p) {
             for (int k = 0; k < 27; ++k) w32[k] = (float) p.w[k];
             if (separable_27(w32, p.sep)) p.tapset = TAPS3D_SEP;
         }
-        p.kernel_name = (p.dtype == LORA_BF16) ? kernel_name_3d_bf16(p) : (p.generic ? kernel_name_generic(p) : kernel_name_3d(p));
+        // two applications per launch (kernels_3d_fused.hip): fp64 tiled path; default, as in 2D (star3d1r 512^3
+        // 499 vs 288 GStencils/s, box3d1r 768^3 523 vs 300)
+        p.steps_per_launch = (p.dtype == LORA_F64 && !p.generic && p.steps_per_launch_req != 1) ? 2 : 1;
+        p.kernel_name = (p.dtype == LORA_BF16) ? kernel_name_3d_bf16(p)
+                        : p.generic            ? kernel_name_generic(p)
+                        : p.steps_per_launch == 2 ? kernel_name_3d_fused2(p)
+                                                  : kernel_name_3d(p);
     } else {
         p.tapset = 0;
         p.kernel_name = kernel_name_1d(p);
@@ -450,9 +456,13 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         p.fused_rows_req = value;
     } else if (!std::strcmp(key, "steps_per_launch")) {
         if (value < 0 || value > 2) return LORA_EINVAL;
-        if (value == 2 && (p.ndim != 2 || p.variant != LORA_VARIANT_DIRECT || p.generic)) return LORA_EUNSUPPORTED;
+        const bool fusable = (p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && !p.generic) ||
+                             (p.ndim == 3 && p.dtype == LORA_F64 && !p.generic);
+        if (value == 2 && !fusable) return LORA_EUNSUPPORTED;
         p.steps_per_launch_req = value;
-        if (p.ndim != 2) p.steps_per_launch = 1;
+    } else if (!std::strcmp(key, "fused_z_chunk")) {
+        if (value < 0 || value > 4096) return LORA_EINVAL;
+        p.fused_z_chunk = value;
     } else {
         return LORA_EINVAL;
     }
@@ -491,6 +501,8 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.fused_rows;
     else if (!std::strcmp(key, "steps_per_launch"))
         *value = p.steps_per_launch;
+    else if (!std::strcmp(key, "fused_z_chunk"))
+        *value = p.fused_z_chunk;
     else if (!std::strcmp(key, "tapset"))
         *value = p.tapset;
     else if (!std::strcmp(key, "variant"))
@@ -522,11 +534,15 @@ int lora_plan_step(lora_plan *plan, const void *d_in, void *d_out, void *stream)
 int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream) {
     if (!plan) return LORA_EINVAL;
     Plan &p = plan->p;
-    if (p.ndim != 2 || p.variant != LORA_VARIANT_DIRECT || p.generic) return LORA_EUNSUPPORTED;
+    const bool ok2 = p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && !p.generic;
+    const bool ok3 = p.ndim == 3 && p.dtype == LORA_F64 && !p.generic;
+    if (!ok2 && !ok3) return LORA_EUNSUPPORTED;
     if (int rc = lora::check_buffers(d_in, d_out)) return rc;
     if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
-    const hipError_t e = lora::launch_2d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),
-                                                begin, end, static_cast<hipStream_t>(stream));
+    const hipError_t e = ok2 ? lora::launch_2d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),
+                                                      begin, end, static_cast<hipStream_t>(stream))
+                             : lora::launch_3d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),
+                                                      begin, end, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) {
         lora::set_last_error("fused kernel launch", e);
         return LORA_EHIP;
@@ -574,7 +590,10 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
         if (int rc = halo(buf[1], buf[0], lora::HALO_COPY, "halo copy")) return rc;
     }
     int done = 0;
-    const bool can_fuse = p.steps_per_launch == 2 && p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && !p.generic;
+    // 3D fused launches implement the reference boundary only (level-1 halo = 0)
+    const bool can_fuse = p.steps_per_launch == 2 && !p.generic &&
+                          ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) ||
+                           (p.ndim == 3 && p.dtype == LORA_F64 && !dirichlet));
     if (can_fuse && times >= 4) {
         // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes the other one,
         // so while fused launches run BOTH physical buffers carry buffer 0's halo; an even number of them leaves

@@ -64,6 +64,7 @@ struct Plan {
     int lds_dma = 0;          // 3D bf16: global_load_lds ring, two planes ahead (hand-counted vmcnt)
     int persistent = 0;       // 2D fused: persistent workgroups with register prefetch of the next tile
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
+    int fused_z_chunk = 0;    // 3D fused: output planes per workgroup (0 = auto: 32, shorter on small grids)
     int steps_per_launch_req = 0;  // 0 = auto (fused for the diamond / star tap sets), 1, 2
     int steps_per_launch = 1;      // resolved
     bool generic = false;  // odd innermost extent: rows are only 8-byte aligned, the tiled kernels do not apply
@@ -92,6 +93,9 @@ enum HaloMode { HALO_COPY = 0, HALO_ZERO = 1, HALO_WRAP = 2 };
 hipError_t launch_halo(const Plan &p, void *dst, const void *src, int mode, hipStream_t s);
 const char *kernel_name_2d_fused2(const Plan &p);
 hipError_t launch_3d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+// two applications per launch, level 1 in LDS (fp64, reference boundary: level-1 halo = 0)
+hipError_t launch_3d_fused2(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+const char *kernel_name_3d_fused2(const Plan &p);
 // any size, any taps (odd innermost extents): one thread per point
 hipError_t launch_2d_generic(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 hipError_t launch_3d_generic(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);

@@ -291,7 +291,65 @@ def test_fused_step2_direct_call_and_regions(L, O):
     torch.cuda.synchronize()
     assert np.array_equal(dst.cpu().numpy(), exp)
     with pytest.raises(L.LoraError):
-        L.Plan("star3d1r", (8, 8, 8)).set_option("steps_per_launch", 2)
+        L.Plan("star3d1r", (8, 8, 8), dtype="bf16").set_option("steps_per_launch", 2)  # fp64 only in 3D
+    with pytest.raises(L.LoraError):
+        L.Plan("1d1r", (64,)).set_option("steps_per_launch", 2)
+
+
+@pytest.mark.parametrize("shape", ["star3d1r", "box3d1r"])
+@pytest.mark.parametrize("dims", [(40, 60, 128), (9, 31, 62), (37, 29, 190), (3, 5, 2), (70, 64, 64)])
+def test_3d_fused_two_step_launches_equal_step_by_step(L, O, shape, dims):
+    """kernels_3d_fused.hip: two applications per launch with time level 1 in LDS.  Same taps in the same order at
+    both levels, so the whole padded buffer (interior and the halo state the step-by-step driver leaves behind)
+    equals the oracle bit for bit while values are exact integers, and to rounding afterwards."""
+    a = O.reference_input(shape, dims)
+    assert L.Plan(shape, dims).set_option("steps_per_launch", 2).kernel_name == "stencil3d_fused2_kernel"
+    for t in (4, 5, 6, 7, 9):
+        exp = O.run(shape, a, t)
+        for zc in (0, 1, 3, 8):
+            got = plan_run(L, shape, a, t, options={"steps_per_launch": 2, "fused_z_chunk": zc})
+            if np.abs(exp).max() < 2.0 ** 53:
+                assert np.array_equal(got, exp), f"{shape} {dims} t={t} zc={zc}"
+            else:
+                assert rel_err(got, exp) < 1e-13, f"{shape} {dims} t={t} zc={zc}"
+
+
+def test_3d_fused_step2_regions_and_real_weights(L, O):
+    import torch
+
+    rng = np.random.default_rng(5)
+    for shape in ("star3d1r", "box3d1r"):
+        dims = (33, 47, 132)
+        a = rng.standard_normal(O.padded_shape(shape, dims))
+        w = rng.standard_normal(27) if shape == "box3d1r" else O.effective_weights(shape) / 8.0
+        if shape == "box3d1r":
+            w /= np.abs(w).sum()
+        exp = O.run(shape, a, 2, weights=w)  # buffer 0 after two sweeps: interior + the input halo
+        plan = L.Plan(shape, dims).set_weights(w).set_option("steps_per_launch", 2)
+        src = torch.from_numpy(a).cuda()
+        dst = torch.from_numpy(a).cuda()
+        dst[1:-1, 2:-2, 4:-4] = -1.0
+        plan.step2(src, dst)
+        torch.cuda.synchronize()
+        got = dst.cpu().numpy()
+        assert np.array_equal(got[0], a[0]) and np.array_equal(got[:, :2], a[:, :2])  # halo untouched
+        assert rel_err(got, exp) < 1e-14, shape
+        whole = got.copy()
+        dst[1:-1, 2:-2, 4:-4] = -1.0
+        for b, e in ((20, 33), (0, 7), (7, 20)):  # plane ranges in any order
+            plan.step2_region(src, dst, b, e)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), whole), shape  # regions == one launch, bit for bit
+        # long run, odd tail, against the oracle to rounding
+        for t in (12, 13):
+            got = plan_run(L, shape, a, t, weights=w, options={"steps_per_launch": 2})
+            assert rel_err(got, O.run(shape, a, t, weights=w)) < 1e-13, (shape, t)
+        # Dirichlet runs fall back to single sweeps (the fused kernel implements the reference boundary only)
+        b0 = torch.from_numpy(a).cuda()
+        b1 = torch.zeros_like(b0)
+        plan.set_boundary("dirichlet").run(b0, b1, 6)
+        torch.cuda.synchronize()
+        assert rel_err(b0.cpu().numpy(), O.run_bc(shape, a, 6, "dirichlet", weights=w)) < 1e-13
 
 
 def test_fused_long_run_real_weights(L, O):
