@@ -10,7 +10,7 @@ single-GPU kernels)::
       [ pad ][ G ghost rows of the upper neighbour ][ ml own rows ][ G ghost rows of the lower one ][ pad ]
 
 * Ghost rows are ordinary interior rows of the local problem.  A launch that advances the grid by ``need`` rows of
-  reach (radius x applications per launch: 3 or 6 in 2D, 1 in 3D, 4 in 1D) is run on the own rows plus the ghost rows
+  reach (radius x applications per launch: 3 or 6 in 2D, 1 or 2 in 3D, 4 in 1D) is run on the own rows plus the ghost rows
   that are still needed later, after which ``need`` fewer ghost rows are valid.  Ghost zones are G = need x E deep and
   are refreshed from the neighbours' own rows every E launches (communication-avoiding: E x fewer, E x larger
   messages -- at 8 GPUs a 2048 x 16384 slab sweeps in ~65 us, so per-launch host work and P2P latency, not
@@ -19,8 +19,8 @@ single-GPU kernels)::
   (it runs on the process group's own stream) and the interior is swept while the messages are in flight.
 * A rank at a global edge has no ghost rows there: its pad rows are the global halo and keep the reference's
   semantics untouched (never written: the caller's input halo at even time levels, zeros at odd ones).
-* 2D shapes with the 25- or 13-tap sets use the fused two-application launches (``Plan.step2_region``) exactly like
-  the single-GPU driver: both physical buffers then carry the level-0 halo ring, odd tails are single sweeps.
+* 2D and (fp64) 3D shapes use the fused two-application launches (``Plan.step2_region``) exactly like the
+  single-GPU driver: both physical buffers then carry the level-0 halo ring, odd tails are single sweeps.
 
 Per-point arithmetic is identical to the single-GPU sweep (same kernels, same tap order), so an N-rank result is
 bit-identical to the 1-rank result.
@@ -72,6 +72,11 @@ class SlabLayout:
     @property
     def halo0(self) -> int:
         return ops.halo(self.shape)[0]
+
+    @property
+    def halos(self) -> tuple:
+        """Pad cells per side of every dimension of the padded layout."""
+        return tuple(ops.halo(self.shape))
 
     @property
     def radius0(self) -> int:
@@ -141,7 +146,7 @@ class SlabDriver:
         probe = slab_layout(sid, global_dims, self.world_size, self.rank)
         radius = probe.radius0
         if fused is None:
-            fused = (nd == 2)  # refined below by what the stepper supports
+            fused = nd in (2, 3)  # refined below by what the stepper supports
         self.dtype = ops.dtype_id(dtype)
         self.torch_dtype = torch.bfloat16 if self.dtype == ops.DTYPES["bf16"] else torch.float64
         if self.dtype == ops.DTYPES["bf16"]:
@@ -182,7 +187,7 @@ class SlabDriver:
         self.steps_done = 0
         self.cur = 0  # physical buffer holding the current time level
         self.valid = layout.ghost  # ghost rows per side that hold the current time level
-        self.ring = ["input", "zero"]  # what the halo ring of each physical buffer holds (fused 2D bookkeeping)
+        self.ring = ["input", "zero"]  # what the halo ring of each physical buffer holds (fused-launch bookkeeping)
 
     # ---- data movement between the global padded array and the slabs ---------------------------------
     def load_global(self, global_padded) -> None:
@@ -227,23 +232,20 @@ class SlabDriver:
             return None
         return torch.cat(pieces, dim=0)
 
-    # ---- halo-ring bookkeeping of the fused 2D path -----------------------------------------------------
+    # ---- halo-ring bookkeeping of the fused path -----------------------------------------------------
     def _set_ring(self, b: int, what: str, src: int) -> None:
         """Global-edge halo ring of physical buffer b: 'input' (copy of buffer src's ring) or 'zero'."""
-        if self.ndim != 2 or self.ring[b] == what:
+        if self.ndim < 2 or self.ring[b] == what:
             return
         t = self.buf[b]
-        if what == "zero":
-            t[:4].zero_()
-            t[-4:].zero_()
-            t[:, :4].zero_()
-            t[:, -4:].zero_()
-        else:
-            s = self.buf[src]
-            t[:4].copy_(s[:4])
-            t[-4:].copy_(s[-4:])
-            t[:, :4].copy_(s[:, :4])
-            t[:, -4:].copy_(s[:, -4:])
+        s = self.buf[src]
+        for d, k in enumerate(self.layout.halos):  # 2D: 4, 4; 3D: 1, 2, 4 cells on either side
+            for side in (slice(0, k), slice(-k, None)):
+                idx = (slice(None),) * d + (side,)
+                if what == "zero":
+                    t[idx].zero_()
+                else:
+                    t[idx].copy_(s[idx])
         self.ring[b] = what
 
     # ---- ghost exchange ---------------------------------------------------------------------------------
@@ -276,7 +278,7 @@ class SlabDriver:
         src_i, dst_i = self.cur, 1 - self.cur
         src, dst = self.buf[src_i], self.buf[dst_i]
         sweep = self.stepper.step2_region if fused else self.stepper.step_region
-        if self.ndim == 2 and (self.fused or fused):
+        if self.ndim >= 2 and (self.fused or fused):
             # fused launches need the level-0 ring in both buffers; a single sweep from an even level writes the
             # odd level, whose ring is 0; from an odd level it writes an even one (ring = input)
             even = self.steps_done % 2 == 0
