@@ -223,8 +223,9 @@ void plan_refresh(Plan &p) {
         }
         // two applications per launch (kernels_3d_fused.hip): fp64 tiled path; default, as in 2D (star3d1r 512^3
         // 499 vs 288 GStencils/s, box3d1r 768^3 523 vs 300)
-        p.steps_per_launch = (p.dtype == LORA_F64 && !p.generic && p.steps_per_launch_req != 1) ? 2 : 1;
-        p.kernel_name = (p.dtype == LORA_BF16) ? kernel_name_3d_bf16(p)
+        p.steps_per_launch = (!p.generic && p.steps_per_launch_req != 1) ? 2 : 1;
+        p.kernel_name = (p.dtype == LORA_BF16)
+                            ? (p.steps_per_launch == 2 ? kernel_name_3d_bf16_fused2(p) : kernel_name_3d_bf16(p))
                         : p.generic            ? kernel_name_generic(p)
                         : p.steps_per_launch == 2 ? kernel_name_3d_fused2(p)
                                                   : kernel_name_3d(p);
@@ -457,7 +458,7 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "steps_per_launch")) {
         if (value < 0 || value > 2) return LORA_EINVAL;
         const bool fusable = (p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && !p.generic) ||
-                             (p.ndim == 3 && p.dtype == LORA_F64 && !p.generic);
+                             (p.ndim == 3 && !p.generic);
         if (value == 2 && !fusable) return LORA_EUNSUPPORTED;
         p.steps_per_launch_req = value;
     } else if (!std::strcmp(key, "fused_z_chunk")) {
@@ -535,12 +536,14 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
     if (!plan) return LORA_EINVAL;
     Plan &p = plan->p;
     const bool ok2 = p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && !p.generic;
-    const bool ok3 = p.ndim == 3 && p.dtype == LORA_F64 && !p.generic;
+    const bool ok3 = p.ndim == 3 && !p.generic;
     if (!ok2 && !ok3) return LORA_EUNSUPPORTED;
     if (int rc = lora::check_buffers(d_in, d_out)) return rc;
     if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
     const hipError_t e = ok2 ? lora::launch_2d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),
                                                       begin, end, static_cast<hipStream_t>(stream))
+                         : p.dtype == LORA_BF16
+                             ? lora::launch_3d_bf16_fused2(p, d_in, d_out, begin, end, static_cast<hipStream_t>(stream))
                              : lora::launch_3d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),
                                                       begin, end, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) {
@@ -593,7 +596,7 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
     // 3D fused launches implement the reference boundary only (level-1 halo = 0)
     const bool can_fuse = p.steps_per_launch == 2 && !p.generic &&
                           ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) ||
-                           (p.ndim == 3 && p.dtype == LORA_F64 && !dirichlet));
+                           (p.ndim == 3 && !dirichlet));
     if (can_fuse && times >= 4) {
         // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes the other one,
         // so while fused launches run BOTH physical buffers carry buffer 0's halo; an even number of them leaves

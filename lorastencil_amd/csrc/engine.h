@@ -102,6 +102,8 @@ hipError_t launch_3d_generic(const Plan &p, const double *in, double *out, int b
 const char *kernel_name_generic(const Plan &p);
 hipError_t launch_3d_bf16(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s);
 const char *kernel_name_3d_bf16(const Plan &p);
+hipError_t launch_3d_bf16_fused2(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s);
+const char *kernel_name_3d_bf16_fused2(const Plan &p);
 
 const char *kernel_name_1d(const Plan &p);
 const char *kernel_name_2d_direct(const Plan &p);

@@ -457,6 +457,218 @@ hipError_t launch_bf16(const Plan &p, const void *in, void *out, int begin, int 
     return hipGetLastError();
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// TWO applications per launch (temporal fusion), the bf16 counterpart of kernels_3d_fused.hip.  Time level 1 is
+// rounded to bf16 exactly as a single sweep would store it and lives in LDS tile B in the input's format, so both
+// levels run the same window code and the result is bit-identical to two single bf16 sweeps (either summation
+// form).  Level-1 cells outside the interior are 0 (the reference driver's "buffer 1" halo).
+//
+// Geometry (256 threads; a wave = 2 row groups x 32 lanes, a lane owns 4 adjacent columns x RY rows, 8 strips):
+//   output tile    8 RY - 2 rows x 120 columns (lanes 1..30 of a row group), padded origin (2 + 30 ty, 4 + 120 tx)
+//   level-1 tile   8 RY rows     x 128 columns, starts 1 row / 4 columns earlier (padded column = 0 mod 8)
+//   input window   8 RY + 2 rows x 144 columns, starts 2 rows / 12 columns earlier: whole 16-byte pieces
+// A lane's level-1 and level-2 columns coincide (padded 120 tx + 4 cl), so both levels read the 12-element window
+// at tile column 4 cl + 4 of A resp. B.  Plane pipeline and accumulator rotation: see kernels_3d_fused.hip.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFusedLanes = 32;
+constexpr int kFusedOutW = 4 * (kFusedLanes - 2);  // 120
+constexpr int kFusedLdsW = 4 * kFusedLanes + 16;   // 144 staged columns = LDS row stride of A and B
+constexpr int kFusedChunks = kFusedLdsW / 8;       // 18 pieces of 16 bytes per row
+
+template <int TAPSET, int RY>
+__global__ __launch_bounds__(256, 3) void stencil3d_bf16_fused2_kernel(const Args3Dh a, const Taps27f W) {
+    constexpr int MH = 8 * RY;
+    constexpr int OH = MH - 2;
+    constexpr int IH = MH + 2;
+    constexpr int NCHUNK = IH * kFusedChunks;
+    constexpr int NIT = (NCHUNK + 255) / 256;
+    __shared__ u32x4 A[NCHUNK];
+    __shared__ u32x4 B[NCHUNK];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = tid >> 6;
+    const int sid = wv * 2 + lane / kFusedLanes;
+    const int cl = lane % kFusedLanes;
+
+    const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int per_chunk = a.tiles_x * a.tiles_y;
+    const int chunk = lin / per_chunk;
+    const int rem = lin - chunk * per_chunk;
+    const int ty = rem / a.tiles_x;
+    const int tx = rem - ty * a.tiles_x;
+    const int k0 = a.z_begin + chunk * a.zc;
+    const int zc = min(a.zc, a.z_end - k0);
+    const int nplanes = zc + 4;
+    const int I = ty * OH;          // first output row (interior)
+    const int J = tx * kFusedOutW;  // first output column (interior), multiple of 8
+
+    int goff[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int k = tid + it * 256;
+        const int r = k / kFusedChunks;
+        const int c = k - r * kFusedChunks;
+        const int gr = min(I + r, a.m + 3);                  // padded rows I .. I + IH - 1
+        const int gc = min(max(J - 8 + 8 * c, 0), a.n);      // padded columns J - 8 .. in 8-element pieces
+        goff[it] = gr * a.ld + gc;
+    }
+    u32x4 stage[NIT];
+    auto load_plane = [&](int p) {
+        const u16 *src = a.in + (long) min(max(k0 - 1 + p, 0), a.h + 1) * a.plane;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            if (NCHUNK % 256 == 0 || tid + it * 256 < NCHUNK) stage[it] = *reinterpret_cast<const u32x4 *>(src + goff[it]);
+        }
+    };
+    auto write_plane = [&]() {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int k = tid + it * 256;
+            if (NCHUNK % 256 == 0 || k < NCHUNK) A[k] = stage[it];
+        }
+    };
+
+    f2 acc1[3][RY][2], acc2[3][RY][2];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int r = 0; r < RY; ++r)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) acc1[s][r][c] = acc2[s][r][c] = (f2){0.0f, 0.0f};
+
+    // this lane's 4 columns at BOTH levels: interior J - 4 + 4 cl .. (tile column 4 cl + 8)
+    const int col = J - 4 + 4 * cl;
+    const bool col_in = col >= 0 && col < a.n;                       // n is a multiple of 8
+    const bool col_out = cl >= 1 && cl <= kFusedLanes - 2 && col < a.n;
+    const int row1 = I - 1 + sid * RY;  // first level-1 row (interior) of the strip
+    const int rowo = I + sid * RY;      // first output row
+    const int strip_off = (sid * RY) * kFusedLdsW + 4 * cl + 4;  // window = tile columns 4 cl + 4 .. 4 cl + 15
+    u16 *const out_col = a.out + (long) (rowo + 2) * a.ld + (col + 4);
+
+    load_plane(0);
+    write_plane();
+    __syncthreads();
+
+    auto sweep_tile = [&](const u32x4 *tile, f2 (&acc)[3][RY][2], auto phase_tag) {
+        constexpr int PHASE = decltype(phase_tag)::value;
+        const u16 *strip = reinterpret_cast<const u16 *>(tile) + strip_off;
+        f2 u[RY][2];
+#pragma unroll
+        for (int j = 0; j < RY + 2; ++j) {
+            unsigned d[6];
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const u32x2 v = *reinterpret_cast<const u32x2 *>(strip + j * kFusedLdsW + 4 * q);
+                d[2 * q] = v.x;
+                d[2 * q + 1] = v.y;
+            }
+            f2 pr[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) pr[k] = (f2){win_elem(d, 3 + k), win_elem(d, 4 + k)};
+            accumulate_row<TAPSET, RY, 2, PHASE>(acc, u, pr, j, W);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int r = 0; r < RY; ++r) asm volatile("" : "+v"(acc[s][r][0]), "+v"(acc[s][r][1]));
+    };
+
+    auto consume = [&](int p, auto phase_tag) {
+        constexpr int PH = decltype(phase_tag)::value;
+        constexpr int PH2 = (PH + 2) % 3;
+        const bool more = p + 1 < nplanes;
+        if (more) load_plane(p + 1);
+
+        sweep_tile(A, acc1, std::integral_constant<int, PH>{});
+        {   // level-1 plane p-1 (interior k0-3+p): round to bf16, 0 outside the interior, publish in B
+            constexpr int s = (PH + 1) % 3;
+            const int z1 = k0 - 3 + p;
+            const bool z_in = z1 >= 0 && z1 < a.h;
+            u16 *dstB = reinterpret_cast<u16 *>(B) + strip_off + 4;
+#pragma unroll
+            for (int r = 0; r < RY; ++r) {
+                const bool in = z_in && col_in && row1 + r >= 0 && row1 + r < a.m;
+                u32x2 v;
+                v.x = in ? pack_bf16(acc1[s][r][0].x, acc1[s][r][0].y) : 0u;
+                v.y = in ? pack_bf16(acc1[s][r][1].x, acc1[s][r][1].y) : 0u;
+                *reinterpret_cast<u32x2 *>(dstB + r * kFusedLdsW) = v;
+                if constexpr (TAPSET != TAPS3D_SEP) acc1[s][r][0] = acc1[s][r][1] = (f2){0.0f, 0.0f};
+            }
+        }
+        __syncthreads();
+
+        sweep_tile(B, acc2, std::integral_constant<int, PH2>{});
+        // refill A first: its wait for the prefetched plane then does not include this iteration's stores
+        if (more) write_plane();
+        {   // output plane k0 + p - 4 is complete in slot PH
+            constexpr int s = PH;
+            const int o = p - 4;
+            if (o >= 0 && o < zc && col_out) {
+                u16 *dst = out_col + (long) (k0 + o + 1) * a.plane;
+#pragma unroll
+                for (int r = 0; r < RY; ++r) {
+                    if (sid * RY + r < OH && rowo + r < a.m) {
+                        u32x2 v;
+                        v.x = pack_bf16(acc2[s][r][0].x, acc2[s][r][0].y);
+                        v.y = pack_bf16(acc2[s][r][1].x, acc2[s][r][1].y);
+                        *reinterpret_cast<u32x2 *>(dst + (long) r * a.ld) = v;
+                    }
+                }
+            }
+            if constexpr (TAPSET != TAPS3D_SEP) {
+#pragma unroll
+                for (int r = 0; r < RY; ++r) acc2[s][r][0] = acc2[s][r][1] = (f2){0.0f, 0.0f};
+            }
+        }
+        __syncthreads();
+    };
+
+    for (int p = 0; p < nplanes; p += 3) {
+        consume(p, std::integral_constant<int, 0>{});
+        if (p + 1 < nplanes) consume(p + 1, std::integral_constant<int, 1>{});
+        if (p + 2 < nplanes) consume(p + 2, std::integral_constant<int, 2>{});
+    }
+}
+
+template <int TAPSET>
+hipError_t launch_bf16_fused2(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s) {
+    constexpr int RY = 4, OH = 8 * RY - 2;
+    Args3Dh a;
+    a.in = static_cast<const u16 *>(in);
+    a.out = static_cast<u16 *>(out);
+    a.h = p.dims[0];
+    a.m = p.dims[1];
+    a.n = p.dims[2];
+    a.ld = a.n + 8;
+    a.plane = (long) (a.m + 4) * (a.n + 8);
+    if (a.plane >= (1L << 31)) return hipErrorInvalidValue;  // 32-bit in-plane offsets
+    a.z_begin = begin;
+    a.z_end = end;
+    a.tiles_x = (a.n + kFusedOutW - 1) / kFusedOutW;
+    a.tiles_y = (a.m + OH - 1) / OH;
+    a.ablate = 0;
+    int zc = p.fused_z_chunk;
+    if (zc <= 0) {  // every chunk re-reads 4 planes: long chunks while they leave a few rounds of 3 workgroups per CU
+        zc = 32;
+        const long per_plane = (long) a.tiles_x * a.tiles_y;
+        while (zc > 8 && per_plane * ((end - begin + zc - 1) / zc) < 6 * 768) zc /= 2;
+    }
+    a.zc = zc;
+    const long chunks = ((long) end - begin + a.zc - 1) / a.zc;
+    const long nblocks = chunks * a.tiles_x * a.tiles_y;
+    if (nblocks <= 0) return hipSuccess;
+    if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
+    Taps27f w;
+    for (int k = 0; k < 27; ++k) w.w[k] = (float) p.w[k];
+    if (TAPSET == TAPS3D_SEP)
+        for (int k = 0; k < 9; ++k) w.w[k] = p.sep[k];
+    hipLaunchKernelGGL((stencil3d_bf16_fused2_kernel<TAPSET, RY>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
+    return hipGetLastError();
+}
+
 }  // namespace
 
 hipError_t launch_3d_bf16(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s) {
@@ -469,5 +681,14 @@ hipError_t launch_3d_bf16(const Plan &p, const void *in, void *out, int begin, i
 }
 
 const char *kernel_name_3d_bf16(const Plan &) { return "stencil3d_bf16_kernel"; }
+
+hipError_t launch_3d_bf16_fused2(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s) {
+    if (end <= begin) return hipSuccess;
+    if (p.tapset == TAPS3D_SEP) return launch_bf16_fused2<TAPS3D_SEP>(p, in, out, begin, end, s);
+    if (p.tapset == TAPS3D_STAR) return launch_bf16_fused2<TAPS3D_STAR>(p, in, out, begin, end, s);
+    return launch_bf16_fused2<TAPS3D_BOX>(p, in, out, begin, end, s);
+}
+
+const char *kernel_name_3d_bf16_fused2(const Plan &) { return "stencil3d_bf16_fused2_kernel"; }
 
 }  // namespace lora

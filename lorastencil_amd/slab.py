@@ -149,8 +149,6 @@ class SlabDriver:
             fused = nd in (2, 3)  # refined below by what the stepper supports
         self.dtype = ops.dtype_id(dtype)
         self.torch_dtype = torch.bfloat16 if self.dtype == ops.DTYPES["bf16"] else torch.float64
-        if self.dtype == ops.DTYPES["bf16"]:
-            fused = False  # the bf16 kernels are the 3D single-sweep ones
         self._make_stepper = stepper_factory or (
             lambda lay: HipStepper(lay, params=params, weights=weights, dtype=self.dtype))
         # thinnest slab of the decomposition bounds the ghost depth (neighbours supply ghost rows from own rows)

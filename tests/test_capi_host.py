@@ -158,7 +158,9 @@ def test_bf16_conversion_matches_oracle(L):
         L.Plan("star2d1r", (64, 128), dtype="bf16")  # bf16 is a 3D-only path
     with pytest.raises(L.LoraError):
         L.Plan("box3d1r", (8, 8, 12), dtype="bf16")  # innermost extent must be a multiple of 8
-    assert L.Plan("box3d1r", (8, 8, 16), dtype="bf16").kernel_name == "stencil3d_bf16_kernel"
+    assert L.Plan("box3d1r", (8, 8, 16), dtype="bf16").kernel_name == "stencil3d_bf16_fused2_kernel"
+    assert L.Plan("box3d1r", (8, 8, 16), dtype="bf16").set_option("steps_per_launch", 1).kernel_name == \
+        "stencil3d_bf16_kernel"
 
 
 def test_shape_tables(L):

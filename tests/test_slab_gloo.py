@@ -58,22 +58,18 @@ class OracleStepper:
 class OracleStepperBf16:
     """bf16 stand-in for HipStepper (tests only): tensors are torch.bfloat16, the oracle works on bit patterns."""
 
-    wants_fused = False
+    wants_fused = True
 
     def __init__(self, layout, weights):
         self.shape = layout.shape
         self.w = np.ascontiguousarray(weights, dtype=np.float32)
         self.calls = {"step": 0, "step2": 0}
 
-    def step_region(self, src, dst, begin, end):
+    def _sweep(self, s):
         import ctypes
 
         from oracle import oracle as O
 
-        self.calls["step"] += 1
-        if end <= begin:
-            return
-        s = np.ascontiguousarray(src.view(torch.int16).numpy().view(np.uint16)[begin:end + 2])
         out = np.zeros_like(s)
         u16 = ctypes.POINTER(ctypes.c_uint16)
         fp = ctypes.POINTER(ctypes.c_float)
@@ -84,6 +80,24 @@ class OracleStepperBf16:
         else:
             O.lib().oracle_step_3d_bf16(s.ctypes.data_as(u16), out.ctypes.data_as(u16), self.w.ctypes.data_as(fp),
                                         *s.shape, 1)
+        return out
+
+    def step2_region(self, src, dst, begin, end):
+        """Two applications, level 1 = 0 outside the local interior (lora_plan_step2_region on bf16 grids)."""
+        self.calls["step2"] += 1
+        if end <= begin:
+            return
+        mid = self._sweep(np.ascontiguousarray(src.view(torch.int16).numpy().view(np.uint16)))  # halo stays 0
+        out = self._sweep(mid)
+        d = dst.view(torch.int16).numpy().view(np.uint16)
+        d[1 + begin:1 + end, 2:-2, 4:-4] = out[1 + begin:1 + end, 2:-2, 4:-4]
+
+    def step_region(self, src, dst, begin, end):
+        self.calls["step"] += 1
+        if end <= begin:
+            return
+        s = np.ascontiguousarray(src.view(torch.int16).numpy().view(np.uint16)[begin:end + 2])
+        out = self._sweep(s)
         d = dst.view(torch.int16).numpy().view(np.uint16)[begin:end + 2]
         d[1:-1, 2:-2, 4:-4] = out[1:-1, 2:-2, 4:-4]
 
