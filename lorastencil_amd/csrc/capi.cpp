@@ -461,6 +461,8 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
                              (p.ndim == 3 && !p.generic);
         if (value == 2 && !fusable) return LORA_EUNSUPPORTED;
         p.steps_per_launch_req = value;
+    } else if (!std::strcmp(key, "fused_pipeline")) {
+        p.fused_pipeline = value ? 1 : 0;
     } else if (!std::strcmp(key, "fused_z_chunk")) {
         if (value < 0 || value > 4096) return LORA_EINVAL;
         p.fused_z_chunk = value;
@@ -504,6 +506,8 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.steps_per_launch;
     else if (!std::strcmp(key, "fused_z_chunk"))
         *value = p.fused_z_chunk;
+    else if (!std::strcmp(key, "fused_pipeline"))
+        *value = p.fused_pipeline;
     else if (!std::strcmp(key, "tapset"))
         *value = p.tapset;
     else if (!std::strcmp(key, "variant"))

@@ -64,6 +64,7 @@ struct Plan {
     int lds_dma = 0;          // 3D bf16: global_load_lds ring, two planes ahead (hand-counted vmcnt)
     int persistent = 0;       // 2D fused: persistent workgroups with register prefetch of the next tile
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
+    int fused_pipeline = 0;   // 3D bf16 fused: 1 = level 2 one plane behind level 1, one barrier per plane (no gain measured)
     int fused_z_chunk = 0;    // 3D fused: output planes per workgroup (0 = auto: 32, shorter on small grids)
     int steps_per_launch_req = 0;  // 0 = auto (fused for the diamond / star tap sets), 1, 2
     int steps_per_launch = 1;      // resolved

@@ -82,6 +82,13 @@ struct Args3Dh {
     int ablate;  // timing-only diagnostics: 1 = no stores, 2 = no plane loads (results are then wrong)
 };
 
+// acc + w * x as ONE unpacked v_fmac_f32 (inline asm: hipcc's SLP pass would otherwise re-pack two of them into a
+// v_pk_fma_f32 and pay for the odd-aligned register pair with v_movs)
+__device__ __forceinline__ float fmac_scalar(float w, float x, float acc) {
+    asm("v_fmac_f32_e32 %0, %1, %2" : "+v"(acc) : "s"(w), "v"(x));
+    return acc;
+}
+
 // One staged row `j` of plane phase PHASE applied to the rotating output-plane accumulators of a lane.
 // pr[k] = window elements (3+k, 4+k) as an fp32 pair; NP column pairs per lane.  Called from fully unrolled loops,
 // so j and every register index is a compile-time constant after inlining.
@@ -90,11 +97,15 @@ __device__ __forceinline__ void accumulate_row(f2 (&acc)[3][RY][NP], f2 (&u)[RY]
                                                const Taps27f &W) {
     if constexpr (TAPSET == TAPS3D_SEP) {
         // W.w[0..2] = c (x), [3..5] = b (y), [6..8] = a (z)
+        // x-pass.  The outer taps read the window as the ALIGNED pairs (3,4), (5,6), .. -- each element converted once,
+        // one packed op per pair; the middle tap straddles two pairs and is applied per element (a packed op would
+        // need every element converted a second time into an odd-aligned pair: 2 conversions + 1 op instead of 2 ops)
         f2 t[NP];
 #pragma unroll
         for (int c = 0; c < NP; ++c) {
             t[c] = (f2){W.w[0], W.w[0]} * pr[2 * c];
-            t[c] = __builtin_elementwise_fma((f2){W.w[1], W.w[1]}, pr[2 * c + 1], t[c]);
+            t[c].x = fmac_scalar(W.w[1], pr[2 * c].y, t[c].x);
+            t[c].y = fmac_scalar(W.w[1], pr[2 * c + 2].x, t[c].y);
             t[c] = __builtin_elementwise_fma((f2){W.w[2], W.w[2]}, pr[2 * c + 2], t[c]);
         }
 #pragma unroll
@@ -476,15 +487,18 @@ constexpr int kFusedOutW = 4 * (kFusedLanes - 2);  // 120
 constexpr int kFusedLdsW = 4 * kFusedLanes + 16;   // 144 staged columns = LDS row stride of A and B
 constexpr int kFusedChunks = kFusedLdsW / 8;       // 18 pieces of 16 bytes per row
 
-template <int TAPSET, int RY>
+// PIPE: both tiles double-buffered (39 KB) and level 2 runs one plane behind level 1 -- iteration p sweeps input
+// plane p from A[p & 1] AND level-1 plane p-2 from B[(p-1) & 1] back to back, then publishes level-1 plane p-1 in
+// B[p & 1] and refills A[(p+1) & 1]: ONE barrier per plane instead of two, at the price of one more iteration.
+template <int TAPSET, int RY, bool PIPE>
 __global__ __launch_bounds__(256, 3) void stencil3d_bf16_fused2_kernel(const Args3Dh a, const Taps27f W) {
     constexpr int MH = 8 * RY;
     constexpr int OH = MH - 2;
     constexpr int IH = MH + 2;
     constexpr int NCHUNK = IH * kFusedChunks;
     constexpr int NIT = (NCHUNK + 255) / 256;
-    __shared__ u32x4 A[NCHUNK];
-    __shared__ u32x4 B[NCHUNK];
+    __shared__ u32x4 A[PIPE ? 2 : 1][NCHUNK];
+    __shared__ u32x4 B[PIPE ? 2 : 1][NCHUNK];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -500,7 +514,6 @@ __global__ __launch_bounds__(256, 3) void stencil3d_bf16_fused2_kernel(const Arg
     const int tx = rem - ty * a.tiles_x;
     const int k0 = a.z_begin + chunk * a.zc;
     const int zc = min(a.zc, a.z_end - k0);
-    const int nplanes = zc + 4;
     const int I = ty * OH;          // first output row (interior)
     const int J = tx * kFusedOutW;  // first output column (interior), multiple of 8
 
@@ -522,11 +535,11 @@ __global__ __launch_bounds__(256, 3) void stencil3d_bf16_fused2_kernel(const Arg
             if (NCHUNK % 256 == 0 || tid + it * 256 < NCHUNK) stage[it] = *reinterpret_cast<const u32x4 *>(src + goff[it]);
         }
     };
-    auto write_plane = [&]() {
+    auto write_plane = [&](int buf) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int k = tid + it * 256;
-            if (NCHUNK % 256 == 0 || k < NCHUNK) A[k] = stage[it];
+            if (NCHUNK % 256 == 0 || k < NCHUNK) A[buf][k] = stage[it];
         }
     };
 
@@ -548,7 +561,7 @@ __global__ __launch_bounds__(256, 3) void stencil3d_bf16_fused2_kernel(const Arg
     u16 *const out_col = a.out + (long) (rowo + 2) * a.ld + (col + 4);
 
     load_plane(0);
-    write_plane();
+    write_plane(0);
     __syncthreads();
 
     auto sweep_tile = [&](const u32x4 *tile, f2 (&acc)[3][RY][2], auto phase_tag) {
@@ -576,60 +589,72 @@ __global__ __launch_bounds__(256, 3) void stencil3d_bf16_fused2_kernel(const Arg
             for (int r = 0; r < RY; ++r) asm volatile("" : "+v"(acc[s][r][0]), "+v"(acc[s][r][1]));
     };
 
-    auto consume = [&](int p, auto phase_tag) {
-        constexpr int PH = decltype(phase_tag)::value;
-        constexpr int PH2 = (PH + 2) % 3;
-        const bool more = p + 1 < nplanes;
-        if (more) load_plane(p + 1);
-
-        sweep_tile(A, acc1, std::integral_constant<int, PH>{});
-        {   // level-1 plane p-1 (interior k0-3+p): round to bf16, 0 outside the interior, publish in B
-            constexpr int s = (PH + 1) % 3;
-            const int z1 = k0 - 3 + p;
-            const bool z_in = z1 >= 0 && z1 < a.h;
-            u16 *dstB = reinterpret_cast<u16 *>(B) + strip_off + 4;
+    // level-1 plane of interior index z1, complete in slot `s` of acc1: round to bf16, 0 outside the interior
+    auto publish = [&](u32x4 *tile, int z1, auto slot_tag) {
+        constexpr int s = decltype(slot_tag)::value;
+        const bool z_in = z1 >= 0 && z1 < a.h;
+        u16 *dstB = reinterpret_cast<u16 *>(tile) + strip_off + 4;
+#pragma unroll
+        for (int r = 0; r < RY; ++r) {
+            const bool in = z_in && col_in && row1 + r >= 0 && row1 + r < a.m;
+            u32x2 v;
+            v.x = in ? pack_bf16(acc1[s][r][0].x, acc1[s][r][0].y) : 0u;
+            v.y = in ? pack_bf16(acc1[s][r][1].x, acc1[s][r][1].y) : 0u;
+            *reinterpret_cast<u32x2 *>(dstB + r * kFusedLdsW) = v;
+            if constexpr (TAPSET != TAPS3D_SEP) acc1[s][r][0] = acc1[s][r][1] = (f2){0.0f, 0.0f};
+        }
+    };
+    // output plane o of the chunk, complete in slot `s` of acc2
+    auto store_plane = [&](int o, auto slot_tag) {
+        constexpr int s = decltype(slot_tag)::value;
+        if (o >= 0 && o < zc && col_out && !(a.ablate & 1)) {
+            u16 *dst = out_col + (long) (k0 + o + 1) * a.plane;
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
-                const bool in = z_in && col_in && row1 + r >= 0 && row1 + r < a.m;
-                u32x2 v;
-                v.x = in ? pack_bf16(acc1[s][r][0].x, acc1[s][r][0].y) : 0u;
-                v.y = in ? pack_bf16(acc1[s][r][1].x, acc1[s][r][1].y) : 0u;
-                *reinterpret_cast<u32x2 *>(dstB + r * kFusedLdsW) = v;
-                if constexpr (TAPSET != TAPS3D_SEP) acc1[s][r][0] = acc1[s][r][1] = (f2){0.0f, 0.0f};
-            }
-        }
-        __syncthreads();
-
-        sweep_tile(B, acc2, std::integral_constant<int, PH2>{});
-        // refill A first: its wait for the prefetched plane then does not include this iteration's stores
-        if (more) write_plane();
-        {   // output plane k0 + p - 4 is complete in slot PH
-            constexpr int s = PH;
-            const int o = p - 4;
-            if (o >= 0 && o < zc && col_out) {
-                u16 *dst = out_col + (long) (k0 + o + 1) * a.plane;
-#pragma unroll
-                for (int r = 0; r < RY; ++r) {
-                    if (sid * RY + r < OH && rowo + r < a.m) {
-                        u32x2 v;
-                        v.x = pack_bf16(acc2[s][r][0].x, acc2[s][r][0].y);
-                        v.y = pack_bf16(acc2[s][r][1].x, acc2[s][r][1].y);
-                        *reinterpret_cast<u32x2 *>(dst + (long) r * a.ld) = v;
-                    }
+                if (sid * RY + r < OH && rowo + r < a.m) {
+                    u32x2 v;
+                    v.x = pack_bf16(acc2[s][r][0].x, acc2[s][r][0].y);
+                    v.y = pack_bf16(acc2[s][r][1].x, acc2[s][r][1].y);
+                    *reinterpret_cast<u32x2 *>(dst + (long) r * a.ld) = v;
                 }
             }
-            if constexpr (TAPSET != TAPS3D_SEP) {
-#pragma unroll
-                for (int r = 0; r < RY; ++r) acc2[s][r][0] = acc2[s][r][1] = (f2){0.0f, 0.0f};
-            }
         }
-        __syncthreads();
+        if constexpr (TAPSET != TAPS3D_SEP) {
+#pragma unroll
+            for (int r = 0; r < RY; ++r) acc2[s][r][0] = acc2[s][r][1] = (f2){0.0f, 0.0f};
+        }
     };
 
-    for (int p = 0; p < nplanes; p += 3) {
+    const int nin = zc + 4;                   // input planes of the chunk
+    const int niter = PIPE ? nin + 1 : nin;
+    auto consume = [&](int p, auto phase_tag) {
+        constexpr int PH = decltype(phase_tag)::value;  // p mod 3
+        const bool more = p + 1 < nin;
+        if (more && !(a.ablate & 2)) load_plane(p + 1);
+        if constexpr (PIPE) {
+            if (p < nin) sweep_tile(A[p & 1], acc1, std::integral_constant<int, PH>{});
+            // level-1 plane p-2 (phase (p-2) mod 3), published during the previous iteration
+            if (p >= 1) sweep_tile(B[(p - 1) & 1], acc2, std::integral_constant<int, (PH + 1) % 3>{});
+            if (p < nin) publish(B[p & 1], k0 - 3 + p, std::integral_constant<int, (PH + 1) % 3>{});
+            if (more) write_plane((p + 1) & 1);
+            store_plane(p - 5, std::integral_constant<int, (PH + 2) % 3>{});  // slot ((p-2) - 2) mod 3
+            __syncthreads();
+        } else {
+            sweep_tile(A[0], acc1, std::integral_constant<int, PH>{});
+            publish(B[0], k0 - 3 + p, std::integral_constant<int, (PH + 1) % 3>{});
+            __syncthreads();
+            sweep_tile(B[0], acc2, std::integral_constant<int, (PH + 2) % 3>{});
+            // refill A first: its wait for the prefetched plane then does not include this iteration's stores
+            if (more) write_plane(0);
+            store_plane(p - 4, std::integral_constant<int, PH>{});
+            __syncthreads();
+        }
+    };
+
+    for (int p = 0; p < niter; p += 3) {
         consume(p, std::integral_constant<int, 0>{});
-        if (p + 1 < nplanes) consume(p + 1, std::integral_constant<int, 1>{});
-        if (p + 2 < nplanes) consume(p + 2, std::integral_constant<int, 2>{});
+        if (p + 1 < niter) consume(p + 1, std::integral_constant<int, 1>{});
+        if (p + 2 < niter) consume(p + 2, std::integral_constant<int, 2>{});
     }
 }
 
@@ -649,12 +674,12 @@ hipError_t launch_bf16_fused2(const Plan &p, const void *in, void *out, int begi
     a.z_end = end;
     a.tiles_x = (a.n + kFusedOutW - 1) / kFusedOutW;
     a.tiles_y = (a.m + OH - 1) / OH;
-    a.ablate = 0;
+    a.ablate = p.ablate;
     int zc = p.fused_z_chunk;
-    if (zc <= 0) {  // every chunk re-reads 4 planes: long chunks while they leave a few rounds of 3 workgroups per CU
-        zc = 32;
+    if (zc <= 0) {  // every chunk re-reads (and re-computes) 4 planes: long chunks while ~3 rounds of 3 per CU remain
+        zc = 32;  // 768^3: 24-32 planes 1600 GStencils/s, 16 -> 1540, 48-64 -> 1490-1560
         const long per_plane = (long) a.tiles_x * a.tiles_y;
-        while (zc > 8 && per_plane * ((end - begin + zc - 1) / zc) < 6 * 768) zc /= 2;
+        while (zc > 8 && per_plane * ((end - begin + zc - 1) / zc) < 3 * 1024) zc /= 2;  // 1024 = 4 per CU
     }
     a.zc = zc;
     const long chunks = ((long) end - begin + a.zc - 1) / a.zc;
@@ -665,7 +690,10 @@ hipError_t launch_bf16_fused2(const Plan &p, const void *in, void *out, int begi
     for (int k = 0; k < 27; ++k) w.w[k] = (float) p.w[k];
     if (TAPSET == TAPS3D_SEP)
         for (int k = 0; k < 9; ++k) w.w[k] = p.sep[k];
-    hipLaunchKernelGGL((stencil3d_bf16_fused2_kernel<TAPSET, RY>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
+    if (p.fused_pipeline)
+        hipLaunchKernelGGL((stencil3d_bf16_fused2_kernel<TAPSET, RY, true>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
+    else
+        hipLaunchKernelGGL((stencil3d_bf16_fused2_kernel<TAPSET, RY, false>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
     return hipGetLastError();
 }
 

@@ -505,7 +505,8 @@ def test_bf16_fused_two_step_launches_equal_step_by_step(L, O, shape, dims):
     assert L.Plan(shape, dims, dtype="bf16").kernel_name == "stencil3d_bf16_fused2_kernel"
     for t in (4, 5, 7, 8):
         exp = O.run_bf16(shape, bits, t, weights=w)
-        for opts in ({}, {"fused_z_chunk": 1}, {"fused_z_chunk": 5}, {"separable": 0}):
+        for opts in ({}, {"fused_z_chunk": 1}, {"fused_z_chunk": 5}, {"separable": 0}, {"fused_pipeline": 1},
+                     {"fused_pipeline": 1, "fused_z_chunk": 2}):
             e = exp if "separable" not in opts else O.run_bf16(shape, bits, t, weights=w, separable=False)
             assert np.array_equal(plan_run_bf16(L, shape, bits, t, weights=w, options=opts), e), (shape, dims, t, opts)
         single = plan_run_bf16(L, shape, bits, t, weights=w, options={"steps_per_launch": 1})
