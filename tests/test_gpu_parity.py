@@ -759,6 +759,16 @@ def test_full_size_constant_field_and_windows(L, O, shape, dims):
     plan.step(src, dst2)
     torch.cuda.synchronize()
     assert bool((dst2 == 2.0 * dst).all())
+    # (4) the default two-applications-per-launch kernel == two single sweeps through a zero-halo buffer, everywhere
+    #     (small integers: exact whatever the summation order of the low-rank evaluation)
+    assert plan.get_option("steps_per_launch") == 2
+    del dst
+    two = src.clone()                 # buffer 0 again after two sweeps: the input's halo, new interior
+    plan.step(dst2, two)              # dst2 = sweep(src) with a zero halo
+    fused = src.clone()
+    plan.step2(src, fused)
+    torch.cuda.synchronize()
+    assert torch.equal(fused, two)
 
 
 def test_full_size_bf16_box3d1r_768(L, O):
@@ -793,6 +803,18 @@ def test_full_size_bf16_box3d1r_768(L, O):
         exp = O.run_bf16(shape, sub, 1, weights=w27)[1:-1, 2:-2, 4:-4]
         got = dst[sl].contiguous().view(torch.int16).cpu().numpy().view(np.uint16)[1:-1, 2:-2, 4:-4]
         assert np.array_equal(got, exp), f"window at {c}"
+    # the fused kernel (default for runs of >= 4 sweeps) == two single sweeps through a zero-halo buffer, everywhere;
+    # normalised taps keep the random field finite in bf16
+    plan.set_weights(w27 / 36.0)
+    assert plan.kernel_name == "stencil3d_bf16_fused2_kernel"
+    dst.zero_()
+    plan.step(src, dst)
+    two = src.clone()
+    plan.step(dst, two)
+    fused = src.clone()
+    plan.step2(src, fused)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.view(torch.int16), two.view(torch.int16))
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -16,5 +16,6 @@ run() {  # tag, bench args...
     cd $ROOT
     tail -1 gpurun_out/p3f_${tag}_bench.log | cut -c1-120
 }
+if [ "$1" = "bf16" ]; then run bf16box768 --dtype bf16; exit 0; fi
 run star512 --shape star3d1r
 run box768 --shape box3d1r
