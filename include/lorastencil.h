@@ -166,7 +166,20 @@ int lora_plan_set_boundary(lora_plan *plan, int boundary);
 /* Boundary condition given to plans created afterwards on this thread, i.e. also to the host operators of group A
  * (what the CLIs' --bc flag sets).  Returns the previous value. */
 int lora_set_default_boundary(int boundary);
-/* Integer tuning knob for benchmarking ("rows_per_thread", "panel_width", "steps_per_launch"). */
+/* Integer options.  Results never depend on them except where stated.
+ *   steps_per_launch  0 auto / 1 / 2 : applications per launch in lora_plan_run (2 = temporal fusion; default for
+ *                     every tiled 2D and 3D plan, fp64 and bf16)
+ *   rows_per_thread, panel_width, nt_store, fused_rows, persistent      2D tile shape / block->tile map / stores
+ *   lowrank_valu      -1 auto / 0 / 1 : low-rank evaluation inside the fused 2D kernel (summation order changes:
+ *                     identical while values are exact integers, ~1 ulp afterwards)
+ *   z_chunk, fused_z_chunk             3D output planes per workgroup (single-sweep / fused kernels; 0 = auto)
+ *   separable         -1 auto / 0     bf16: exactly separable taps as x/y/z passes (changes the fp32 summation
+ *                     order; the oracle restates both orders, see lora_separable_3x3x3)
+ *   cols_per_lane, lds_dma, fused_pipeline                              bf16 kernel variants
+ *   graph             -1 auto / 0 / 1 : hipGraph replay of lora_plan_run
+ *   ablate            DIAGNOSTIC, bf16 3D only: 1 = skip stores, 2 = skip plane loads -- timing experiments whose
+ *                     RESULTS ARE WRONG by construction; never set outside profiling
+ * lora_plan_get_option also reads the resolved "tapset", "variant", "fused_eval", "boundary". */
 int lora_plan_set_option(lora_plan *plan, const char *key, int value);
 int lora_plan_get_option(const lora_plan *plan, const char *key, int *value);
 size_t lora_plan_padded_bytes(const lora_plan *plan);
@@ -181,7 +194,7 @@ int lora_plan_step(lora_plan *plan, const void *d_in, void *d_out, void *stream)
  * with the rest.  begin must be a multiple of lora_plan_region_granularity() (2 in 1D, 1 otherwise). */
 int lora_plan_step_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream);
 int lora_plan_region_granularity(const lora_plan *plan);
-/* TWO kernel applications in one launch (temporal fusion; 2D shapes, direct variant): the intermediate time level
+/* TWO kernel applications in one launch (temporal fusion; tiled 2D direct-variant and 3D plans): the intermediate time level
  * lives in LDS and its halo cells are taken as 0 -- the state of the reference driver's second buffer --
  * so d_in must be an even time level (halo = the caller's input halo).  Interior of d_out <- stencil(stencil(d_in)).
  * lora_plan_run uses it when the option "steps_per_launch" is 2. */

@@ -11,7 +11,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblorastencil_hip.so")
+# LORASTENCIL_LIB: another build of the SAME engine (A/B timing of kernel changes on one GPU box); never a fallback
+LIB_PATH = os.environ.get("LORASTENCIL_LIB") or os.path.join(_HERE, "lib", "liblorastencil_hip.so")
 
 LORA_OK = 0
 LORA_EINVAL = -1
