@@ -60,20 +60,34 @@ def main():
         ("box2d3r", (8192, 8192), {"panel_width": [16, 32], "variant": [2]}),
         ("star2d3r", (16384, 16384), {"rows_per_thread": [4, 8], "panel_width": [16, 32], "variant": [1]}),
         ("star2d3r", (16384, 16384), {"panel_width": [32], "variant": [2]}),
-        ("star3d1r", (512, 512, 512), {"z_chunk": [4, 7, 16, 31, 64]}),
-        ("box3d1r", (768, 768, 768), {"z_chunk": [7, 16, 31]}),
-        ("star3d1r", (64, 512, 512), {"z_chunk": [4, 7, 16]}),
+        ("star3d1r", (512, 512, 512), {"steps_per_launch": [1], "z_chunk": [4, 7, 16, 31, 64]}),
+        ("box3d1r", (768, 768, 768), {"steps_per_launch": [1], "z_chunk": [7, 16, 31]}),
+        ("star3d1r", (64, 512, 512), {"steps_per_launch": [1], "z_chunk": [4, 7, 16]}),
+        # 3D temporal fusion: output planes per workgroup (every chunk re-reads 4 planes)
+        ("star3d1r", (512, 512, 512), {"steps_per_launch": [2], "fused_z_chunk": [8, 12, 16, 24, 32, 64]}),
+        ("box3d1r", (768, 768, 768), {"steps_per_launch": [2], "fused_z_chunk": [8, 16, 24, 32, 64]}),
+        ("star3d1r", (64, 512, 512), {"steps_per_launch": [2], "fused_z_chunk": [0, 8, 16, 32]}),
+        ("box3d1r", (768, 768, 768), {"steps_per_launch": [1], "separable": [0, 1]}, "bf16"),
+        ("box3d1r", (768, 768, 768), {"steps_per_launch": [2], "separable": [0, 1],
+                                      "fused_z_chunk": [12, 16, 24, 32, 48, 64]}, "bf16"),
+        ("box3d1r", (768, 768, 768), {"steps_per_launch": [2], "fused_pipeline": [0, 1]}, "bf16"),
+        ("star3d1r", (768, 768, 768), {"steps_per_launch": [1, 2]}, "bf16"),
         ("1d1r", (1048576,), {}),
         ("1d1r", (1 << 28,), {}),
     ]
-    for shape, dims, grid in cases:
-        if args.only and args.only not in shape:
+    for case in cases:
+        shape, dims, grid = case[:3]
+        dtype = case[3] if len(case) > 3 else "f64"
+        if args.only and args.only not in shape and args.only != dtype:
             continue
-        plan = L.Plan(shape, dims)
+        if args.only == "3d" and len(dims) != 3:
+            continue
+        plan = L.Plan(shape, dims, dtype=dtype)
+        esize = 2 if dtype == "bf16" else 8
         w = plan.weights
         plan.set_weights(w / w.sum())  # normalised taps: values stay bounded however many sweeps are timed
         ps = plan.padded_shape
-        src = torch.randint(0, 100, ps, device=dev).to(torch.float64)
+        src = torch.randint(0, 100, ps, device=dev).to(torch.bfloat16 if dtype == "bf16" else torch.float64)
         dst = torch.zeros_like(src)
         pts = 1
         for d in dims:
@@ -87,25 +101,26 @@ def main():
                 else:
                     plan.set_option(k, v)
             iters = 5 if args.quick else 20
-            spl = plan.get_option("steps_per_launch") if len(dims) == 2 else 1
+            spl = plan.get_option("steps_per_launch") if len(dims) >= 2 else 1
             if spl == 2:
                 t = time_fn(lambda: plan.step2(src, dst), iters) / 2.0  # per application
             else:
                 t = time_fn(lambda: plan.step(src, dst), iters)
-            record(kind="sweep", shape=shape, dims=dims, options=dict(zip(keys, combo)), kernel=plan.kernel_name,
-                   seconds=t, gstencils=pts / t / 1e9, algo_gbs=pts * 16 / t / 1e9, frac_of_8TBs=pts * 16 / t / 8e12)
+            record(kind="sweep", shape=shape, dims=dims, dtype=dtype, options=dict(zip(keys, combo)),
+                   kernel=plan.kernel_name, seconds=t, gstencils=pts / t / 1e9, algo_gbs=pts * 2 * esize / t / 1e9,
+                   frac_of_8TBs=pts * 2 * esize / t / 8e12)
         del src, dst
         torch.cuda.empty_cache()
 
     best = {}
     for r in rows:
         if r["kind"] == "sweep":
-            key = (r["shape"], tuple(r["dims"]))
+            key = (r["shape"], tuple(r["dims"]), r.get("dtype", "f64"))
             if key not in best or r["gstencils"] > best[key]["gstencils"]:
                 best[key] = r
     print("\nBEST per case:")
     for k, r in best.items():
-        print(f"  {k[0]:10s} {str(k[1]):22s} {r['options']}  {r['gstencils']:.1f} GSt/s  {r['algo_gbs']:.0f} GB/s  "
+        print(f"  {k[0]:10s} {str(k[1]):22s} {k[2]:5s} {r['options']}  {r['gstencils']:.1f} GSt/s  {r['algo_gbs']:.0f} GB/s  "
               f"{100 * r['frac_of_8TBs']:.1f}% of 8 TB/s")
 
 
