@@ -238,7 +238,7 @@ def main():
     value = points * K / elapsed / 1e9
     # one launch applies `spl` sweeps (temporal fusion); algorithmic bytes stay 2 x 8 B per point per APPLICATION
     if world == 1:
-        spl = plan.get_option("steps_per_launch") if len(dims) == 2 else 1
+        spl = plan.get_option("steps_per_launch")
     else:
         spl = 2 if drv.fused else 1
     launches = max(1, K // spl) if spl > 1 else K
@@ -285,6 +285,8 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
+                # the same launch duration applied to the MEASURED bytes: the real HBM rate behind `achieved`
+                "traffic_gbs": round(traffic / launch_s / 1e9, 1) if traffic else None,
                 "launch_us": round(launch_s * 1e6, 2),
                 "bytes_per_launch": round(bytes_per_launch),
                 "applications_per_launch": spl,

@@ -167,8 +167,8 @@ int lora_plan_set_boundary(lora_plan *plan, int boundary);
  * (what the CLIs' --bc flag sets).  Returns the previous value. */
 int lora_set_default_boundary(int boundary);
 /* Integer options.  Results never depend on them except where stated.
- *   steps_per_launch  0 auto / 1 / 2 : applications per launch in lora_plan_run (2 = temporal fusion; default for
- *                     every tiled 2D and 3D plan, fp64 and bf16)
+ *   steps_per_launch  0 auto / 1 / 2 (1D also 4, 8) : applications per launch in lora_plan_run (temporal fusion;
+ *                     default 2 for every tiled 2D and 3D plan, fp64 and bf16, and 8 in 1D)
  *   rows_per_thread, panel_width, nt_store, fused_rows, persistent      2D tile shape / block->tile map / stores
  *   lowrank_valu      -1 auto / 0 / 1 : low-rank evaluation inside the fused 2D kernel (summation order changes:
  *                     identical while values are exact integers, ~1 ulp afterwards)
@@ -200,6 +200,12 @@ int lora_plan_region_granularity(const lora_plan *plan);
  * lora_plan_run uses it when the option "steps_per_launch" is 2. */
 int lora_plan_step2(lora_plan *plan, const void *d_in, void *d_out, void *stream);
 int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream);
+/* The plan's resolved "steps_per_launch" applications in ONE launch: 1 = lora_plan_step, 2 = lora_plan_step2 (2D / 3D),
+ * 2 / 4 / 8 in 1D (intermediate levels in LDS; halo cells of odd intermediate levels are 0, of even ones the source
+ * buffer's halo -- the state the step-by-step driver would leave).  d_in must be an even time level.
+ * lora_plan_run uses an even number of these and finishes with single sweeps. */
+int lora_plan_stepk(lora_plan *plan, const void *d_in, void *d_out, void *stream);
+int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream);
 /* The time-step driver (2d/gpu.cu:544-546): `times` applications ping-ponging between the two
  * buffers starting from d_buf0; the result is in buffer [times % 2].  The caller must have put
  * the padded input in d_buf0 and zeros in d_buf1 to get the reference semantics. */

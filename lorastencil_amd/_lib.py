@@ -92,7 +92,9 @@ SIGNATURES = {
     "lora_plan_step_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lora_plan_region_granularity": (ctypes.c_int, [_vp]),
     "lora_plan_step2": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "lora_plan_stepk": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "lora_plan_step2_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "lora_plan_stepk_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lora_plan_run": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),
     "lora_plan_destroy": (None, [_vp]),
     "lora_default_params": (ctypes.c_int, [ctypes.c_int, _dp]),

@@ -231,7 +231,9 @@ void plan_refresh(Plan &p) {
                                                   : kernel_name_3d(p);
     } else {
         p.tapset = 0;
-        p.kernel_name = kernel_name_1d(p);
+        // K applications per launch (kernels_1d.hip): 8 by default, the single sweep being launch-latency bound
+        p.steps_per_launch = p.steps_per_launch_req == 0 ? 8 : p.steps_per_launch_req;
+        p.kernel_name = p.steps_per_launch > 1 ? kernel_name_1d_fused(p) : kernel_name_1d(p);
     }
 }
 
@@ -456,10 +458,11 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         if (value != 0 && value != 6 && value != 8 && value != 10) return LORA_EINVAL;
         p.fused_rows_req = value;
     } else if (!std::strcmp(key, "steps_per_launch")) {
-        if (value < 0 || value > 2) return LORA_EINVAL;
+        if (value < 0 || value > 8 || (value & (value - 1))) return LORA_EINVAL;  // 0 (auto), 1, 2, 4, 8
         const bool fusable = (p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && !p.generic) ||
-                             (p.ndim == 3 && !p.generic);
-        if (value == 2 && !fusable) return LORA_EUNSUPPORTED;
+                             (p.ndim == 3 && !p.generic) || p.ndim == 1;
+        if (value >= 2 && !fusable) return LORA_EUNSUPPORTED;
+        if (value > 2 && p.ndim != 1) return LORA_EUNSUPPORTED;  // 2D / 3D kernels fuse two applications
         p.steps_per_launch_req = value;
     } else if (!std::strcmp(key, "fused_pipeline")) {
         p.fused_pipeline = value ? 1 : 0;
@@ -562,6 +565,27 @@ int lora_plan_step2(lora_plan *plan, const void *d_in, void *d_out, void *stream
     return lora_plan_step2_region(plan, d_in, d_out, 0, plan->p.dims[0], stream);
 }
 
+int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream) {
+    if (!plan) return LORA_EINVAL;
+    Plan &p = plan->p;
+    if (p.steps_per_launch <= 1) return lora_plan_step_region(plan, d_in, d_out, begin, end, stream);
+    if (p.ndim != 1) return lora_plan_step2_region(plan, d_in, d_out, begin, end, stream);
+    if (int rc = lora::check_buffers(d_in, d_out)) return rc;
+    if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end || (begin & 1)) return LORA_EINVAL;
+    const hipError_t e = lora::launch_1d_fused(p, static_cast<const double *>(d_in), static_cast<double *>(d_out), begin,
+                                               end, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        lora::set_last_error("fused 1D kernel launch", e);
+        return LORA_EHIP;
+    }
+    return LORA_OK;
+}
+
+int lora_plan_stepk(lora_plan *plan, const void *d_in, void *d_out, void *stream) {
+    if (!plan) return LORA_EINVAL;
+    return lora_plan_stepk_region(plan, d_in, d_out, 0, plan->p.dims[0], stream);
+}
+
 // The launches of one run, in order, on `stream` (also what gets captured into a hipGraph).
 static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream) {
     Plan &p = plan->p;
@@ -598,26 +622,27 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
     }
     int done = 0;
     // 3D fused launches implement the reference boundary only (level-1 halo = 0)
-    const bool can_fuse = p.steps_per_launch == 2 && !p.generic &&
-                          ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) ||
-                           (p.ndim == 3 && !dirichlet));
-    if (can_fuse && times >= 4) {
+    const int K = p.steps_per_launch;  // applications per fused launch: 2 (2D, 3D) or 2 / 4 / 8 (1D)
+    const bool can_fuse = K >= 2 && !p.generic &&
+                          ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) || (p.ndim == 3 && !dirichlet) ||
+                           p.ndim == 1);
+    if (can_fuse && times >= 2 * K) {
         // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes the other one,
         // so while fused launches run BOTH physical buffers carry buffer 0's halo; an even number of them leaves
         // the data in buffer 0, after which (reference boundary) buffer 1's halo is put back to 0 and the remaining
         // 0..3 steps are single sweeps -- the result and its halo end up exactly where the step-by-step driver
         // leaves them.  With the Dirichlet boundary both halos simply stay.
         if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
-        const int pairs = (times / 2) & ~1;
+        const int pairs = (times / K) & ~1;
         if (!dirichlet)
             if (int rc = halo(buf[1], buf[0], lora::HALO_COPY, "halo copy")) return rc;
         for (int k = 0; k < pairs; ++k) {
-            const int rc = lora_plan_step2(plan, buf[k % 2], buf[(k + 1) % 2], stream);
+            const int rc = lora_plan_stepk(plan, buf[k % 2], buf[(k + 1) % 2], stream);
             if (rc != LORA_OK) return rc;
         }
         if (!dirichlet)
             if (int rc = halo(buf[1], nullptr, lora::HALO_ZERO, "halo reset")) return rc;
-        done = 2 * pairs;
+        done = K * pairs;
     }
     for (int i = done; i < times; ++i) {  // 2d/gpu.cu:544-546
         const int rc = lora_plan_step(plan, buf[i % 2], buf[(i + 1) % 2], stream);

@@ -66,7 +66,7 @@ struct Plan {
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
     int fused_pipeline = 0;   // 3D bf16 fused: 1 = level 2 one plane behind level 1, one barrier per plane (no gain measured)
     int fused_z_chunk = 0;    // 3D fused: output planes per workgroup (0 = auto: 32, shorter on small grids)
-    int steps_per_launch_req = 0;  // 0 = auto (fused for the diamond / star tap sets), 1, 2
+    int steps_per_launch_req = 0;  // 0 = auto, 1, 2 (2D / 3D), 2 / 4 / 8 (1D)
     int steps_per_launch = 1;      // resolved
     bool generic = false;  // odd innermost extent: rows are only 8-byte aligned, the tiled kernels do not apply
     int lowrank_valu = -1;    // 2D fused: low-rank evaluation on the vector pipe: -1 auto, 0 off, 1 on when the factors fit
@@ -85,6 +85,9 @@ void plan_refresh(Plan &p);  // re-derive tapset / low-rank factors / kernel nam
 // ---- kernel launchers (kernels_*.hip).  Interior index range [begin, end) of the outermost
 // dimension; all return the launch status. ----------------------------------------------------
 hipError_t launch_1d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+// steps_per_launch (2 / 4 / 8) applications per launch, intermediate levels in LDS
+hipError_t launch_1d_fused(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
+const char *kernel_name_1d_fused(const Plan &p);
 hipError_t launch_2d_direct(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 hipError_t launch_2d_mfma(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 // two applications per launch (intermediate level in LDS, its halo = 0); 2D direct taps only

@@ -47,7 +47,127 @@ __global__ __launch_bounds__(256) void stencil1d_kernel(const double *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// K applications per launch (temporal fusion).  At the reference's size the single sweep is bound
+// by launch latency and L2 round trips (~4 us per step whatever the kernel does), so the lever is fewer launches:
+// a workgroup loads the window of its 2048 outputs plus 4 K points on either side into LDS once, applies the 9 taps
+// K times ping-ponging between two LDS arrays -- the valid range shrinks by 4 points per side and level -- and stores
+// level K.  Same taps, same order as the single sweep at every level: bit-identical to K launches.
+//
+// Boundary semantics of the step-by-step driver: halo cells are never written, so at ODD time levels
+// (buffer 1) they hold 0 and at EVEN levels (buffer 0) the caller's input halo.  A fused launch starts at an even
+// level; cells outside the interior are therefore forced to 0 at odd intermediate levels and to the source buffer's
+// halo value at even ones (the Dirichlet option: the source's halo value at every level).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kFusedOut = 2048;  // outputs per workgroup
+
+struct ArgsFused1D {
+    const double *in;
+    double *out;
+    int n;           // interior points
+    int begin, end;  // interior range of this launch (even begin)
+    int dirichlet;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void stencil1d_fusedk_kernel(const ArgsFused1D a, const Taps9 W) {
+    constexpr int WIN = kFusedOut + 8 * K;
+    __shared__ __attribute__((aligned(16))) double L[2][WIN];
+    const int tid = threadIdx.x;
+    const int t0 = a.begin + (int) blockIdx.x * kFusedOut;  // first output (interior index, even)
+    const int w0 = t0 + 4 - 4 * K;                          // padded index of window element 0 (even)
+    const int npad = a.n + 8;
+
+    // level 0: the window, 0 where the padded array ends
+    for (int i = 2 * tid; i < WIN; i += 512) {
+        const int g = w0 + i;
+        d2 v;
+        if (g >= 0 && g + 1 < npad) {
+            v = *reinterpret_cast<const d2 *>(a.in + g);
+        } else {
+            v.x = (g >= 0 && g < npad) ? a.in[g] : 0.0;
+            v.y = (g + 1 >= 0 && g + 1 < npad) ? a.in[g + 1] : 0.0;
+        }
+        *reinterpret_cast<d2 *>(&L[0][i]) = v;
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int l = 1; l <= K; ++l) {
+        const double *src = L[(l - 1) & 1];
+        double *dst = L[l & 1];
+        // level l is defined on window elements [4 l, WIN - 4 l)
+        constexpr int NPAIR_IT = (WIN - 8 + 511) / 512;  // compile-time trip count: the LDS reads of all iterations overlap
+#pragma unroll
+        for (int it = 0; it < NPAIR_IT; ++it) {
+            const int i = 4 * l + 2 * tid + 512 * it;
+            if (i >= WIN - 4 * l) break;
+            double win[10];
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const d2 v = *reinterpret_cast<const d2 *>(src + i - 4 + 2 * q);
+                win[2 * q] = v.x;
+                win[2 * q + 1] = v.y;
+            }
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                a0 = fma(W.w[t], win[t], a0);
+                a1 = fma(W.w[t], win[t + 1], a1);
+            }
+            const int g = w0 + i;  // padded index of the pair's first point
+            if (l < K) {
+                // intermediate level: halo cells keep their driver state instead of a computed value
+                const bool keep = a.dirichlet || (l & 1) == 0;
+                if (!(g >= 4 && g < a.n + 4)) a0 = (keep && g >= 0 && g < npad) ? a.in[g] : 0.0;
+                if (!(g + 1 >= 4 && g + 1 < a.n + 4)) a1 = (keep && g + 1 >= 0 && g + 1 < npad) ? a.in[g + 1] : 0.0;
+                d2 v;
+                v.x = a0;
+                v.y = a1;
+                *reinterpret_cast<d2 *>(dst + i) = v;
+            } else {
+                const int o = g - 4;  // interior index
+                if (o + 1 < a.end && o + 1 < a.n) {
+                    d2 v;
+                    v.x = a0;
+                    v.y = a1;
+                    *reinterpret_cast<d2 *>(a.out + g) = v;
+                } else if (o < a.end && o < a.n) {
+                    a.out[g] = a0;
+                }
+            }
+        }
+        if (l < K) __syncthreads();
+    }
+}
+
 }  // namespace
+
+hipError_t launch_1d_fused(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
+    if (end <= begin) return hipSuccess;
+    if (begin & 1) return hipErrorInvalidValue;
+    ArgsFused1D a;
+    a.in = in;
+    a.out = out;
+    a.n = p.dims[0];
+    a.begin = begin;
+    a.end = end;
+    a.dirichlet = p.boundary == LORA_BC_DIRICHLET;
+    Taps9 w;
+    for (int t = 0; t < 9; ++t) w.w[t] = p.w[t];
+    const long blocks = ((long) end - begin + kFusedOut - 1) / kFusedOut;
+    if (p.steps_per_launch == 8)
+        hipLaunchKernelGGL((stencil1d_fusedk_kernel<8>), dim3((unsigned) blocks), dim3(256), 0, s, a, w);
+    else if (p.steps_per_launch == 4)
+        hipLaunchKernelGGL((stencil1d_fusedk_kernel<4>), dim3((unsigned) blocks), dim3(256), 0, s, a, w);
+    else if (p.steps_per_launch == 2)
+        hipLaunchKernelGGL((stencil1d_fusedk_kernel<2>), dim3((unsigned) blocks), dim3(256), 0, s, a, w);
+    else
+        return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+const char *kernel_name_1d_fused(const Plan &) { return "stencil1d_fusedk_kernel"; }
 
 hipError_t launch_1d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
     if (end <= begin) return hipSuccess;

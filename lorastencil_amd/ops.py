@@ -364,6 +364,14 @@ class Plan:
         check(_lib.lib().lora_plan_step2_region(self._h, _ptr(d_in), _ptr(d_out), int(begin), int(end),
                                                 _stream(stream)), "lora_plan_step2_region")
 
+    def stepk(self, d_in, d_out, stream=None):
+        """The plan's ``steps_per_launch`` applications in one launch (d_in must be an even time level)."""
+        check(_lib.lib().lora_plan_stepk(self._h, _ptr(d_in), _ptr(d_out), _stream(stream)), "lora_plan_stepk")
+
+    def stepk_region(self, d_in, d_out, begin: int, end: int, stream=None):
+        check(_lib.lib().lora_plan_stepk_region(self._h, _ptr(d_in), _ptr(d_out), int(begin), int(end),
+                                                _stream(stream)), "lora_plan_stepk_region")
+
     def run(self, d_buf0, d_buf1, times: int, stream=None):
         """`times` sweeps ping-ponging from d_buf0; the result is in buffer [times % 2]."""
         check(_lib.lib().lora_plan_run(self._h, _ptr(d_buf0), _ptr(d_buf1), int(times), _stream(stream)),

@@ -291,7 +291,53 @@ def test_fused_step2_direct_call_and_regions(L, O):
     torch.cuda.synchronize()
     assert np.array_equal(dst.cpu().numpy(), exp)
     with pytest.raises(L.LoraError):
-        L.Plan("1d1r", (64,)).set_option("steps_per_launch", 2)
+        L.Plan("star2d1r", (64, 64)).set_option("steps_per_launch", 4)  # 2D / 3D fuse two applications
+    with pytest.raises(L.LoraError):
+        L.Plan("1d1r", (64,)).set_option("steps_per_launch", 3)
+
+
+@pytest.mark.parametrize("shape", ["1d1r", "1d2r"])
+@pytest.mark.parametrize("n", [1048576, 5000, 4097, 30, 2048, 2050])
+def test_1d_fused_k_step_launches_equal_step_by_step(L, O, shape, n):
+    """stencil1d_fusedk_kernel: 8 (4, 2) applications per launch with the intermediate levels in LDS; halo cells of
+    odd intermediate levels are 0 and of even ones the input halo, as the step-by-step driver leaves them."""
+    import torch
+
+    dims = (n,)
+    a = O.reference_input(shape, dims)
+    assert L.Plan(shape, dims).kernel_name == "stencil1d_fusedk_kernel"
+    assert L.Plan(shape, dims).set_option("steps_per_launch", 1).kernel_name == "stencil1d_kernel"
+    for k in (8, 4, 2):
+        for t in (2 * k, 2 * k + 1, 4 * k + 3):
+            exp = O.run(shape, a, t)[:-1]  # the host operator's copy-back omits the last element (SURVEY B4)
+            got = plan_run(L, shape, a, t, options={"steps_per_launch": k})[:-1]
+            if np.abs(exp).max() < 2.0 ** 53:
+                assert np.array_equal(got, exp), (shape, n, k, t)
+            else:
+                assert rel_err(got, exp) < 1e-13, (shape, n, k, t)
+    # real-valued data, normalised taps, long run through the hipGraph path; Dirichlet option
+    rng = np.random.default_rng(n)
+    b = rng.standard_normal(n + 8)
+    w = O.effective_weights(shape)
+    w = w / w.sum()
+    assert rel_err(plan_run(L, shape, b, 50, weights=w)[:-1], O.run(shape, b, 50, weights=w)[:-1]) < 1e-13
+    plan = L.Plan(shape, dims).set_weights(w).set_boundary("dirichlet")
+    b0 = torch.from_numpy(b).cuda()
+    b1 = torch.zeros_like(b0)
+    plan.run(b0, b1, 35)
+    torch.cuda.synchronize()
+    assert rel_err((b0, b1)[35 % 2].cpu().numpy(), O.run_bc(shape, b, 35, "dirichlet", weights=w)) < 1e-13
+    # one direct K-step launch on point ranges == K single sweeps (the source buffer carries the level-0 halo)
+    plan = L.Plan(shape, dims).set_weights(w)
+    src = torch.from_numpy(b).cuda()
+    dst = src.clone()
+    cuts = sorted({0, (n // 3) & ~1, (2 * n // 3) & ~1, n})
+    for lo, hi in list(zip(cuts[:-1], cuts[1:]))[::-1]:
+        plan.stepk_region(src, dst, lo, hi)
+    torch.cuda.synchronize()
+    exp = O.run(shape, b, 8, weights=w)  # buffer 0 after 8 sweeps: the input's halo, new interior
+    assert rel_err(dst.cpu().numpy()[:-1], exp[:-1]) < 1e-14
+    assert np.array_equal(dst.cpu().numpy()[:4], b[:4]) and np.array_equal(dst.cpu().numpy()[-4:], b[-4:])
 
 
 @pytest.mark.parametrize("shape", ["star3d1r", "box3d1r"])
