@@ -177,7 +177,7 @@ int lora_set_default_boundary(int boundary);
  *                     order; the oracle restates both orders, see lora_separable_3x3x3)
  *   cols_per_lane, lds_dma, fused_pipeline                              bf16 kernel variants
  *   graph             -1 auto / 0 / 1 : hipGraph replay of lora_plan_run
- *   ablate            DIAGNOSTIC, bf16 3D only: 1 = skip stores, 2 = skip plane loads -- timing experiments whose
+ *   ablate            DIAGNOSTIC (2D fused and bf16 3D kernels): 1 = skip stores, 2 = skip loads -- timing experiments whose
  *                     RESULTS ARE WRONG by construction; never set outside profiling
  * lora_plan_get_option also reads the resolved "tapset", "variant", "fused_eval", "boundary". */
 int lora_plan_set_option(lora_plan *plan, const char *key, int value);

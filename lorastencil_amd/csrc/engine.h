@@ -60,7 +60,7 @@ struct Plan {
     int cols_per_lane = 4;    // 3D bf16: 4 (512-byte row pieces per wave) or 8 (1 KiB)
     int separable = -1;       // 3D bf16: evaluate exactly-separable taps as x/y/z passes: -1 auto (= on), 0 off
     float sep[9] = {0};       // resolved factors c(x), b(y), a(z) when tapset == TAPS3D_SEP
-    int ablate = 0;           // diagnostics only (3D bf16): 1 = skip stores, 2 = skip plane loads
+    int ablate = 0;           // diagnostics only (2D fused, 3D bf16): 1 = skip stores, 2 = skip loads; results wrong
     int lds_dma = 0;          // 3D bf16: global_load_lds ring, two planes ahead (hand-counted vmcnt)
     int persistent = 0;       // 2D fused: persistent workgroups with register prefetch of the next tile
     int z_chunk = 16;         // 3D: output planes streamed per workgroup

@@ -117,6 +117,7 @@ struct ArgsFused {
     int row_begin, row_end;
     int tiles_x, tiles_y, panel_w;
     int dirichlet;  // intermediate cells outside the interior keep the input halo value instead of 0
+    int ablate;     // timing-only diagnostics: 1 = no stores, 2 = no window loads (results are then wrong)
 };
 
 // PERSIST: the grid is 3 workgroups per CU; each walks its XCD's run of tiles and fetches the next tile's input
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256, 3) void stencil2d_fused2_kernel(const ArgsFuse
             }
         }
     };
-    fetch(lin);
+    if (!(a.ablate & 2)) fetch(lin);
 
     for (; lin < lin_end; lin += stride) {
     int ty, tx;
@@ -288,7 +289,7 @@ __global__ __launch_bounds__(256, 3) void stencil2d_fused2_kernel(const ArgsFuse
                 const int r = j - 6;
                 const int ro = wv * R2 + r;  // output row inside the tile
                 const int row = i0 + ro;
-                if (col_ok && ro < TH && row < a.row_end) {
+                if (col_ok && ro < TH && row < a.row_end && !(a.ablate & 1)) {
                     d2 v;
                     v.x = acc0[r];
                     v.y = acc1[r];
@@ -319,6 +320,7 @@ hipError_t launch_fused2_t(const Plan &p, const double *in, double *out, int beg
     a.tiles_y = (end - begin + TH - 1) / TH;
     a.panel_w = p.panel_width < 1 ? 1 : (p.panel_width > a.tiles_x ? a.tiles_x : p.panel_width);
     a.dirichlet = p.boundary == LORA_BC_DIRICHLET;
+    a.ablate = p.ablate;
     Taps49 w;
     for (int k = 0; k < 49; ++k) w.w[k] = p.w[k];
     LowRankTaps f{};
