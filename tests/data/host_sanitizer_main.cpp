@@ -27,6 +27,14 @@ int main() {
     int dims[3] = {7, 9, 16};
     if (lora_padded_count(LORA_BOX3D1R, dims) != 9u * 13u * 24u) return 6;
     if (lora_shape_from_name("star2d1r") != LORA_STAR2D1R || lora_shape_from_name(nullptr) >= 0) return 7;
+    float cba[9];
+    lora_default_params(LORA_BOX3D1R, p);
+    lora_effective_weights(LORA_BOX3D1R, p, w);
+    if (lora_separable_3x3x3(w, cba) != 1 || cba[1] != 2.0f) return 8;      // reference box3d1r: c = (1, 2, 1)
+    lora_effective_weights(LORA_STAR3D1R, nullptr, w);
+    if (lora_separable_3x3x3(w, cba) != 0) return 9;
+    for (int k = 0; k < 27; ++k) w[k] = 0.0;
+    if (lora_separable_3x3x3(w, cba) != 0 || lora_separable_3x3x3(nullptr, cba) >= 0) return 10;
     std::puts("SAN_OK");
     return 0;
 }
