@@ -624,8 +624,7 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
     // 3D fused launches implement the reference boundary only (level-1 halo = 0)
     const int K = p.steps_per_launch;  // applications per fused launch: 2 (2D, 3D) or 2 / 4 / 8 (1D)
     const bool can_fuse = K >= 2 && !p.generic &&
-                          ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) || (p.ndim == 3 && !dirichlet) ||
-                           p.ndim == 1);
+                          ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) || p.ndim == 3 || p.ndim == 1);
     if (can_fuse && times >= 2 * K) {
         // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes the other one,
         // so while fused launches run BOTH physical buffers carry buffer 0's halo; an even number of them leaves

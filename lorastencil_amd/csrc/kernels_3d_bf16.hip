@@ -80,6 +80,7 @@ struct Args3Dh {
     int zc;
     int tiles_x, tiles_y;
     int ablate;  // timing-only diagnostics: 1 = no stores, 2 = no plane loads (results are then wrong)
+    int dirichlet;  // fused kernel: level-1 cells outside the interior keep the source's halo value instead of 0
 };
 
 // acc + w * x as ONE unpacked v_fmac_f32 (inline asm: hipcc's SLP pass would otherwise re-pack two of them into a
@@ -452,6 +453,7 @@ hipError_t launch_bf16(const Plan &p, const void *in, void *out, int begin, int 
     a.tiles_x = (a.n + kTileW - 1) / kTileW;
     a.tiles_y = (a.m + TY - 1) / TY;
     a.ablate = p.ablate;
+    a.dirichlet = 0;
     const long chunks = ((long) end - begin + a.zc - 1) / a.zc;
     const long nblocks = chunks * a.tiles_x * a.tiles_y;
     if (nblocks <= 0) return hipSuccess;
@@ -600,6 +602,11 @@ __global__ __launch_bounds__(256, 3) void stencil3d_bf16_fused2_kernel(const Arg
             u32x2 v;
             v.x = in ? pack_bf16(acc1[s][r][0].x, acc1[s][r][0].y) : 0u;
             v.y = in ? pack_bf16(acc1[s][r][1].x, acc1[s][r][1].y) : 0u;
+            if (a.dirichlet && !in) {  // fixed boundary: halo cells keep the source's value at every level
+                const int pz = z1 + 1, pr = row1 + r + 2, pc = col + 4;
+                if (pz >= 0 && pz <= a.h + 1 && pr >= 0 && pr <= a.m + 3 && pc >= 0 && pc + 3 <= a.n + 7)
+                    v = *reinterpret_cast<const u32x2 *>(a.in + (long) pz * a.plane + (long) pr * a.ld + pc);
+            }
             *reinterpret_cast<u32x2 *>(dstB + r * kFusedLdsW) = v;
             if constexpr (TAPSET != TAPS3D_SEP) acc1[s][r][0] = acc1[s][r][1] = (f2){0.0f, 0.0f};
         }
@@ -675,6 +682,7 @@ hipError_t launch_bf16_fused2(const Plan &p, const void *in, void *out, int begi
     a.tiles_x = (a.n + kFusedOutW - 1) / kFusedOutW;
     a.tiles_y = (a.m + OH - 1) / OH;
     a.ablate = p.ablate;
+    a.dirichlet = p.boundary == LORA_BC_DIRICHLET;
     int zc = p.fused_z_chunk;
     if (zc <= 0) {  // every chunk re-reads (and re-computes) 4 planes: long chunks while ~3 rounds of 3 per CU remain
         zc = 32;  // 768^3: 24-32 planes 1600 GStencils/s, 16 -> 1540, 48-64 -> 1490-1560

@@ -6,7 +6,8 @@
 // add it to the three level-2 planes it touches.  The reference has no temporal blocking.
 //
 // Semantics = two consecutive launches of the reference driver starting at an EVEN step: level 1 is
-// "buffer 1", whose halo cells are never written and hold 0, so every level-1 cell outside the interior is 0; the
+// "buffer 1", whose halo cells are never written and hold 0, so every level-1 cell outside the interior is 0 (under
+// the Dirichlet option: the source's halo value); the
 // input's halo is whatever the source buffer holds (the driver in capi.cpp keeps the level-0 halo in both physical
 // buffers while fused launches run, exactly as for the 2D fused kernel).  Taps are applied in the single-sweep
 // kernel's order at both levels, so the result is bit-identical to two single sweeps.
@@ -53,6 +54,7 @@ struct ArgsF3 {
     int z_begin, z_end;
     int zc;
     int tiles_x, tiles_y;
+    int dirichlet;  // level-1 cells outside the interior keep the source's halo value instead of 0
 };
 
 // Row `j` of a strip's window (6 doubles, the lane's columns are elements 2 and 3) added, weighted per dz / dy / dx,
@@ -195,6 +197,13 @@ __global__ __launch_bounds__(256, 3) void stencil3d_fused2_kernel(const ArgsF3 a
                 d2 v;
                 v.x = in ? a0[s][r] : 0.0;
                 v.y = in ? a1[s][r] : 0.0;
+                if (a.dirichlet && !in) {
+                    // fixed boundary: a halo cell keeps the caller's value at every level -- read it from the source
+                    // (only lanes on the grid's rim get here; cells beyond the padded array feed no valid output)
+                    const int pz = z1 + 1, pr = row1 + r + 2, pc = col1 + 4;
+                    if (pz >= 0 && pz <= a.h + 1 && pr >= 0 && pr <= a.m + 3 && pc >= 0 && pc + 1 <= a.n + 7)
+                        v = *reinterpret_cast<const d2 *>(a.in + (long) pz * a.plane + (long) pr * a.ld + pc);
+                }
                 *reinterpret_cast<d2 *>(&B[strip_off + r * kInW]) = v;
                 a0[s][r] = 0.0;
                 a1[s][r] = 0.0;
@@ -269,6 +278,7 @@ hipError_t launch_fused3(const Plan &p, const double *in, double *out, int begin
     if (a.plane >= (1L << 31)) return hipErrorInvalidValue;  // 32-bit in-plane offsets
     a.z_begin = begin;
     a.z_end = end;
+    a.dirichlet = p.boundary == LORA_BC_DIRICHLET;
     a.tiles_x = (a.n + kOutW - 1) / kOutW;
     a.tiles_y = (a.m + OH - 1) / OH;
     // every chunk re-reads 4 planes: long chunks while they still leave a few workgroups per CU slot

@@ -654,7 +654,8 @@ def test_graph_replay_of_launch_bound_runs(L, O, shape, dims, t):
 @pytest.mark.parametrize("bc", ["dirichlet", "periodic"])
 @pytest.mark.parametrize("shape,dims", [("star2d1r", (64, 128)), ("star2d1r", (53, 246)), ("box2d3r", (40, 130)),
                                         ("star2d3r", (200, 380)), ("star3d1r", (9, 20, 136)), ("box3d1r", (6, 5, 8)),
-                                        ("1d1r", (4096,)), ("star2d1r", (33, 65))])
+                                        ("1d1r", (4096,)), ("star2d1r", (33, 65)), ("star3d1r", (40, 70, 200)),
+                                        ("box3d1r", (33, 35, 130))])
 def test_boundary_condition_options(L, O, shape, dims, bc):
     """fixed (Dirichlet) and periodic halos as driver options, against the oracle's restatement."""
     import torch
@@ -675,9 +676,28 @@ def test_boundary_condition_options(L, O, shape, dims, bc):
 
 
 def test_boundary_condition_bf16_and_validation(L, O):
+    import torch
+
+    # Dirichlet on bf16 grids: the fused launches (level-1 halo = the source's halo) == single sweeps, bit for bit
+    rng = np.random.default_rng(41)
+    for shape, dims in (("box3d1r", (21, 37, 136)), ("star3d1r", (9, 30, 120))):
+        bits = O.to_bf16(rng.standard_normal(O.padded_shape(shape, dims)))
+        w = O.effective_weights(shape)
+        w = w / w.sum()
+        res = []
+        for spl in (2, 1):
+            plan = L.Plan(shape, dims, dtype="bf16").set_weights(w).set_boundary("dirichlet")
+            plan.set_option("steps_per_launch", spl)
+            b0 = torch.from_numpy(bits.view(np.int16).copy()).cuda().view(torch.bfloat16)
+            b1 = torch.zeros_like(b0)
+            plan.run(b0, b1, 9)
+            torch.cuda.synchronize()
+            res.append(b1.view(torch.int16).cpu().numpy().view(np.uint16))
+        assert np.array_equal(res[0], res[1]), shape
+        assert np.array_equal(res[0][0], bits[0]) and np.array_equal(res[0][:, :2], bits[:, :2])  # halo = the input's
+
     shape, dims = "box3d1r", (6, 10, 64)
     bits = O.to_bf16(O.reference_input(shape, dims))
-    import torch
 
     plan = L.Plan(shape, dims, dtype="bf16").set_boundary("periodic")
     w = O.effective_weights(shape) / 36.0
