@@ -202,6 +202,13 @@ void plan_refresh(Plan &p) {
                 }
             } else if (lr.rank == 3 && lr.nresid == 0 && outside_zero(1, 1) && outside_zero(2, 2)) {
                 p.fused_eval = 4;
+                // mirror-symmetric horizontal profiles (every table the pyramid scheme accepts: it needs a symmetric
+                // matrix): the mirrored taps of a row are pre-added once and shared by the three terms
+                bool sym = p.lowrank_valu != 2;  // lowrank_valu = 2 keeps the plain pyramid form (A/B timing)
+                for (int t = 0; t < 3 && sym; ++t)
+                    for (int e = 0; e < 3; ++e)
+                        if (lr.v[t][e] != lr.v[t][6 - e]) sym = false;
+                if (sym) p.fused_eval = 5;
             }
         }
         p.kernel_name = p.generic ? kernel_name_generic(p)
@@ -442,7 +449,7 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.use_graph = value;
     } else if (!std::strcmp(key, "lowrank_valu")) {
-        if (value < -1 || value > 1) return LORA_EINVAL;
+        if (value < -1 || value > 2) return LORA_EINVAL;
         p.lowrank_valu = value;
     } else if (!std::strcmp(key, "separable")) {
         if (value < -1 || value > 1) return LORA_EINVAL;
