@@ -240,7 +240,7 @@ def main():
     if world == 1:
         spl = plan.get_option("steps_per_launch")
     else:
-        spl = 2 if drv.fused else 1
+        spl = drv.apps if drv.fused else 1
     launches = max(1, K // spl) if spl > 1 else K
     launch_s = ev_ms / 1e3 / launches  # average launch duration on the launch stream (HIP events)
     bytes_per_launch = local_points * 2.0 * esize * (K / launches)

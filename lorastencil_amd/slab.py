@@ -10,7 +10,7 @@ single-GPU kernels)::
       [ pad ][ G ghost rows of the upper neighbour ][ ml own rows ][ G ghost rows of the lower one ][ pad ]
 
 * Ghost rows are ordinary interior rows of the local problem.  A launch that advances the grid by ``need`` rows of
-  reach (radius x applications per launch: 3 or 6 in 2D, 1 or 2 in 3D, 4 in 1D) is run on the own rows plus the ghost rows
+  reach (radius x applications per launch: 3 or 6 in 2D, 1 or 2 in 3D, 4 or 32 in 1D) is run on the own rows plus the ghost rows
   that are still needed later, after which ``need`` fewer ghost rows are valid.  Ghost zones are G = need x E deep and
   are refreshed from the neighbours' own rows every E launches (communication-avoiding: E x fewer, E x larger
   messages -- at 8 GPUs a 2048 x 16384 slab sweeps in ~65 us, so per-launch host work and P2P latency, not
@@ -19,13 +19,13 @@ single-GPU kernels)::
   (it runs on the process group's own stream) and the interior is swept while the messages are in flight.
 * A rank at a global edge has no ghost rows there: its pad rows are the global halo and keep the reference's
   semantics untouched (never written: the caller's input halo at even time levels, zeros at odd ones).
-* 2D and (fp64) 3D shapes use the fused two-application launches (``Plan.step2_region``) exactly like the
-  single-GPU driver: both physical buffers then carry the level-0 halo ring, odd tails are single sweeps.
+* Fused launches (``Plan.stepk_region``: 2 applications in 2D / 3D, 8 in 1D) are used exactly like in the
+  single-GPU driver: both physical buffers then carry the level-0 halo ring, tails are single sweeps.
 
 Per-point arithmetic is identical to the single-GPU sweep (same kernels, same tap order), so an N-rank result is
 bit-identical to the 1-rank result.
 
-The sweep itself is delegated to a *stepper* (``step_region`` / ``step2_region``).  The product stepper is
+The sweep itself is delegated to a *stepper* (``step_region`` / ``stepk_region``).  The product stepper is
 ``HipStepper`` (the HIP engine through ``ops.Plan``); there is no CPU stepper in this package -- the gloo tests
 inject one to exercise the decomposition, ghost-zone bookkeeping and exchange logic on CPU.
 """
@@ -118,14 +118,19 @@ class HipStepper:
         self.stream = int(torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else 0
 
     @property
+    def apps_per_launch(self) -> int:
+        """Applications of one fused launch: 2 in 2D / 3D, 8 in 1D (the plan's resolved steps_per_launch)."""
+        return self.plan.get_option("steps_per_launch")
+
+    @property
     def wants_fused(self) -> bool:
-        return self.plan.get_option("steps_per_launch") == 2
+        return self.apps_per_launch > 1
 
     def step_region(self, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
         self.plan.step_region(src.data_ptr(), dst.data_ptr(), begin, end, stream=self.stream)
 
-    def step2_region(self, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
-        self.plan.step2_region(src.data_ptr(), dst.data_ptr(), begin, end, stream=self.stream)
+    def stepk_region(self, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
+        self.plan.stepk_region(src.data_ptr(), dst.data_ptr(), begin, end, stream=self.stream)
 
 
 class SlabDriver:
@@ -136,6 +141,7 @@ class SlabDriver:
                  exchange_every: int | None = None, fused: bool | None = None, boundary_rows: int | None = None,
                  dtype="f64"):
         self.group = group
+        self._host_side_p2p = dist.is_initialized() and dist.get_backend(group) != "nccl"
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -146,7 +152,7 @@ class SlabDriver:
         probe = slab_layout(sid, global_dims, self.world_size, self.rank)
         radius = probe.radius0
         if fused is None:
-            fused = nd in (2, 3)  # refined below by what the stepper supports
+            fused = True  # refined below by what the stepper supports
         self.dtype = ops.dtype_id(dtype)
         self.torch_dtype = torch.bfloat16 if self.dtype == ops.DTYPES["bf16"] else torch.float64
         self._make_stepper = stepper_factory or (
@@ -156,16 +162,20 @@ class SlabDriver:
         if exchange_every is None:
             exchange_every = 4
         layout = None
-        for try_fused in ([True, False] if fused else [False]):
-            need = radius * (2 if try_fused else 1)
+        default_apps = 8 if nd == 1 else 2  # applications of a fused launch (lora_plan_stepk)
+        for apps in ([default_apps, 1] if fused else [1]):
+            need = radius * apps
             e = max(1, min(exchange_every, thinnest // need if self.world_size > 1 else exchange_every))
             if self.world_size > 1 and thinnest < need:
                 continue
             layout = slab_layout(sid, global_dims, self.world_size, self.rank, ghost=need * e)
             stepper = self._make_stepper(layout)
-            if try_fused and not (hasattr(stepper, "step2_region") and getattr(stepper, "wants_fused", True)):
-                continue  # e.g. 49-tap box: the engine prefers single sweeps
-            self.fused, self.need, self.exchange_every = try_fused, need, e
+            if apps > 1:
+                has = hasattr(stepper, "stepk_region") or hasattr(stepper, "step2_region")
+                if not (has and getattr(stepper, "wants_fused", True)
+                        and getattr(stepper, "apps_per_launch", default_apps) == apps):
+                    continue  # the stepper declines fusion (or fuses a different number of applications)
+            self.fused, self.apps, self.need, self.exchange_every = apps > 1, apps, need, e
             self.stepper = stepper
             break
         if layout is None or not hasattr(self, "stepper"):
@@ -233,7 +243,7 @@ class SlabDriver:
     # ---- halo-ring bookkeeping of the fused path -----------------------------------------------------
     def _set_ring(self, b: int, what: str, src: int) -> None:
         """Global-edge halo ring of physical buffer b: 'input' (copy of buffer src's ring) or 'zero'."""
-        if self.ndim < 2 or self.ring[b] == what:
+        if self.ring[b] == what:
             return
         t = self.buf[b]
         s = self.buf[src]
@@ -251,6 +261,10 @@ class SlabDriver:
         """Own boundary rows of ``t`` -> the neighbours' ghost zones (G rows each way)."""
         lay = self.layout
         g = lay.ghost
+        if t.is_cuda and self._host_side_p2p:
+            # gloo moves device tensors from a CPU thread with no stream ordering (rehearsals of the N > 1 path on one
+            # GPU): the strips just launched must have landed before it reads them.  RCCL is stream-ordered.
+            torch.cuda.current_stream(t.device).synchronize()
         first = lay.halo0 + lay.ghost_top  # padded index of the first own row
         last = first + lay.own
         opsl = []
@@ -272,11 +286,15 @@ class SlabDriver:
     # ---- one launch (1 or 2 applications) ---------------------------------------------------------------
     def _launch(self, fused: bool) -> None:
         lay = self.layout
-        need = self.radius * (2 if fused else 1)
+        apps = self.apps if fused else 1
+        need = self.radius * apps
         src_i, dst_i = self.cur, 1 - self.cur
         src, dst = self.buf[src_i], self.buf[dst_i]
-        sweep = self.stepper.step2_region if fused else self.stepper.step_region
-        if self.ndim >= 2 and (self.fused or fused):
+        if fused:
+            sweep = getattr(self.stepper, "stepk_region", None) or self.stepper.step2_region
+        else:
+            sweep = self.stepper.step_region
+        if self.fused or fused:
             # fused launches need the level-0 ring in both buffers; a single sweep from an even level writes the
             # odd level, whose ring is 0; from an odd level it writes an even one (ring = input)
             even = self.steps_done % 2 == 0
@@ -309,7 +327,7 @@ class SlabDriver:
                 sweep(src, dst, lo, hi)
                 self.valid = left
         self.cur = dst_i
-        self.steps_done += 2 if fused else 1
+        self.steps_done += apps
 
     def step(self) -> None:
         """One kernel application."""
@@ -319,9 +337,9 @@ class SlabDriver:
         """`times` kernel applications (fused pairs where the shape allows, starting at even time levels)."""
         t = 0
         while t < times:
-            if self.fused and self.steps_done % 2 == 0 and times - t >= 2:
+            if self.fused and self.steps_done % 2 == 0 and times - t >= self.apps:
                 self._launch(True)
-                t += 2
+                t += self.apps
             else:
                 self._launch(False)
                 t += 1

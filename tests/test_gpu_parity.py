@@ -961,6 +961,7 @@ def _slab_rank(rank, world, port, shape, dims, times, every, dtype, q):
     ("box2d3r", (300, 130), 6, 3, "f64"),
     ("star3d1r", (24, 20, 64), 7, 2, "f64"),
     ("box3d1r", (24, 20, 64), 6, 3, "bf16"),
+    ("1d1r", (30000,), 27, 2, "f64"),          # 8-step fused launches: 64-point ghost zones
 ])
 def test_three_rank_slabs_on_one_gpu_equal_single_rank(L, O, shape, dims, times, every, dtype):
     import socket
@@ -994,7 +995,7 @@ def test_three_rank_slabs_on_one_gpu_equal_single_rank(L, O, shape, dims, times,
         else:
             assert rel_err(got, exp) < 1e-13
     assert fused  # 2D and 3D, fp64 and bf16: two applications per launch
-    assert ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * (2 if fused else 1) * every
+    assert ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * (8 if len(dims) == 1 else 2) * every
 
 
 def test_rccl_backend_initialises_and_slab_driver_runs_under_it(L, O):

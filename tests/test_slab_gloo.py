@@ -26,20 +26,29 @@ class OracleStepper:
         self.shape = layout.shape
         self.w = weights
         self.h = ops.halo(layout.shape)
-        self.wants_fused = wants_fused and len(self.h) in (2, 3)
+        self.wants_fused = wants_fused
+        self.apps_per_launch = 8 if len(self.h) == 1 else 2
         self.calls = {"step": 0, "step2": 0}
 
-    def step2_region(self, src, dst, begin, end):
-        """Two applications with the intermediate level's out-of-interior cells = 0 (lora_plan_step2_region)."""
+    def stepk_region(self, src, dst, begin, end):
+        """apps_per_launch applications in one call (lora_plan_stepk_region): cells outside the local interior are 0 at
+        odd intermediate levels and the source's halo value at even ones."""
         from oracle import oracle as O
 
         self.calls["step2"] += 1
         if end <= begin:
             return
-        mid = O.step(self.shape, np.ascontiguousarray(src.numpy()), self.w)  # zeros outside the local interior
-        out = O.step(self.shape, mid, self.w)
+        s = np.ascontiguousarray(src.numpy())
+        cur = s
+        for level in range(1, self.apps_per_launch + 1):
+            cur = O.step(self.shape, cur, self.w)  # zeros outside the local interior
+            if level % 2 == 0 and level < self.apps_per_launch:
+                for d, k in enumerate(self.h):
+                    for side in (slice(0, k), slice(-k, None)):
+                        idx = (slice(None),) * d + (side,)
+                        cur[idx] = s[idx]
         idx = (slice(self.h[0] + begin, self.h[0] + end),) + tuple(slice(k, -k) for k in self.h[1:])
-        dst.numpy()[idx] = out[idx]
+        dst.numpy()[idx] = cur[idx]
 
     def step_region(self, src, dst, begin, end):
         from oracle import oracle as O
@@ -214,7 +223,9 @@ def test_slabs_equal_single_rank(engine_built, world, shape, dims, times):
     (3, "box3d1r", (30, 6, 8), 9, 2),
     (2, "star3d1r", (16, 8, 16), 5, 3),
     (3, "box2d3r", (192, 32), 5, 2),      # 49-tap box: the stepper declines fusion
-    (2, "1d2r", (8192,), 5, 2),
+    (2, "1d2r", (8192,), 5, 2),           # fewer steps than one 8-step launch: single sweeps only
+    (2, "1d1r", (8192,), 19, 2),          # 8-step fused launches in 1D: 64-point ghost zones, + 3 single sweeps
+    (3, "1d2r", (12288,), 33, 1),
 ])
 def test_ghost_zone_schedules_equal_single_rank(engine_built, world, shape, dims, times, every):
     from oracle import oracle as O
@@ -227,9 +238,10 @@ def test_ghost_zone_schedules_equal_single_rank(engine_built, world, shape, dims
         expect[-1] = got[-1]
     assert np.array_equal(got, expect)
     radius = {1: 4, 2: 3, 3: 1}[len(dims)]
-    assert e == every and ghost == radius * (2 if was_fused else 1) * every
-    assert was_fused == (len(dims) in (2, 3) and fused is None)
-    if was_fused:
+    apps = (8 if len(dims) == 1 else 2) if was_fused else 1
+    assert e == every and ghost == radius * apps * every
+    assert was_fused == (fused is None)
+    if was_fused and times // 2 >= apps:  # the run is split in two calls of times // 2 and the rest
         assert calls["step2"] > 0
 
 
