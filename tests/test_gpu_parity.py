@@ -776,6 +776,24 @@ def test_slab_driver_single_rank_on_gpu(L, O):
         assert np.array_equal(drv.gather_global().numpy(), O.run(shape, a, t)), shape
 
 
+def test_randomised_parity_against_the_oracle(L, O):
+    """tools/fuzz_parity.py with a fixed seed: random shapes, ragged / odd / tiny sizes, step counts, boundary options,
+    kernel options and taps; whole padded result vs the oracle (bit-exact for integer data and bf16 grids)."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    rng = np.random.default_rng(20261004)
+    kinds = {}
+    for _ in range(300):
+        c = fz.draw_case(rng)
+        ok, how = fz.run_case(c, rng)
+        kinds[how] = kinds.get(how, 0) + 1
+        assert ok, c
+    assert kinds.get("exact", 0) > 20 and kinds.get("bits", 0) > 10 and kinds.get("rel", 0) > 50
+
+
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties + sampled windows against the oracle
 # ---------------------------------------------------------------------------------------------------------

@@ -1,0 +1,142 @@
+#!/usr/bin/env python3
+"""Randomised parity check of the HIP engine against the CPU oracle (development tool; needs a GPU).
+
+Draws shapes, sizes (ragged, tiny, odd), step counts, boundary options, kernel options and taps at random, runs
+lora_plan_run on the device and compares the WHOLE padded result with the oracle: bit for bit while every value is an
+exact integer below 2^53 (or for bf16 grids), to 1e-12 relative otherwise.  Prints one line per failure and a summary;
+exit code 1 on any mismatch."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import lorastencil_amd as L  # noqa: E402
+from oracle import oracle as O  # noqa: E402  (checker only)
+
+SHAPES = ["1d1r", "1d2r", "star2d1r", "box2d1r", "star2d3r", "box2d3r", "star3d1r", "box3d1r"]
+
+
+def draw_case(rng):
+    shape = SHAPES[rng.integers(len(SHAPES))]
+    nd = len(L.ops.halo(shape))
+    bf16 = nd == 3 and rng.random() < 0.35
+    if nd == 1:
+        dims = (int(rng.integers(1, 9000)) if rng.random() < 0.8 else int(rng.integers(9000, 70000)),)
+    elif nd == 2:
+        n = int(rng.integers(1, 200)) * 2 if rng.random() < 0.85 else int(rng.integers(1, 200)) * 2 + 1
+        dims = (int(rng.integers(1, 160)), n)
+    else:
+        n = int(rng.integers(1, 40)) * 8 if bf16 else (int(rng.integers(1, 130)) * 2 if rng.random() < 0.85
+                                                        else int(rng.integers(1, 130)) * 2 + 1)
+        dims = (int(rng.integers(1, 40)), int(rng.integers(1, 70)), n)
+    times = int(rng.integers(0, 20)) if nd == 1 else int(rng.integers(0, 11))
+    bc = ["reference", "reference", "dirichlet", "periodic"][rng.integers(4)]
+    h = L.ops.halo(shape)
+    if bc == "periodic" and any(d < k for d, k in zip(dims, h)):
+        bc = "reference"
+    if bf16 and bc != "reference":
+        bc = "reference"  # the bf16 oracle restates the reference driver only
+    opts = {}
+    if rng.random() < 0.5:
+        opts["steps_per_launch"] = int([1, 2, 4, 8][rng.integers(4)] if nd == 1 else [1, 2][rng.integers(2)])
+    if nd == 3:
+        if rng.random() < 0.5:
+            opts["z_chunk"] = int(rng.integers(1, 20))
+        if rng.random() < 0.5:
+            opts["fused_z_chunk"] = int(rng.integers(0, 12))
+        if bf16 and rng.random() < 0.3:
+            opts["separable"] = 0
+        if bf16 and rng.random() < 0.3:
+            opts["fused_pipeline"] = 1
+        if bf16 and rng.random() < 0.2:
+            opts["lds_dma"] = 1
+    if nd == 2:
+        if rng.random() < 0.4:
+            opts["fused_rows"] = int([6, 8, 10][rng.integers(3)])
+        if rng.random() < 0.3:
+            opts["lowrank_valu"] = int(rng.integers(0, 3))
+        if rng.random() < 0.2:
+            opts["rows_per_thread"] = int([4, 8][rng.integers(2)])
+    kind = ["default", "default", "normalised", "random"][rng.integers(4)]
+    real_input = rng.random() < 0.4
+    return dict(shape=shape, dims=dims, times=times, bc=bc, opts=opts, taps=kind, real_input=real_input, bf16=bf16)
+
+
+def run_case(c, rng):
+    shape, dims = c["shape"], c["dims"]
+    w = O.effective_weights(shape)
+    if c["taps"] == "normalised":
+        w = w / w.sum()
+    elif c["taps"] == "random":
+        mask = w != 0 if shape.startswith("star") else np.ones_like(w, dtype=bool)
+        w = np.where(mask, rng.standard_normal(w.size), 0.0)
+        w = w / max(np.abs(w).sum(), 1e-30)
+    a = rng.standard_normal(O.padded_shape(shape, dims)) if c["real_input"] else O.reference_input(shape, dims)
+    plan = L.Plan(shape, dims, dtype="bf16" if c["bf16"] else "f64").set_weights(w).set_boundary(c["bc"])
+    for k, v in c["opts"].items():
+        try:
+            plan.set_option(k, v)
+        except L.LoraError:
+            pass  # option not applicable to this plan (e.g. fusion on an odd innermost extent)
+    t = c["times"]
+    if c["bf16"]:
+        bits = O.to_bf16(a)
+        b0 = torch.from_numpy(bits.view(np.int16).copy()).cuda().view(torch.bfloat16)
+        b1 = torch.zeros_like(b0)
+        plan.run(b0, b1, t)
+        torch.cuda.synchronize()
+        got = (b0, b1)[t % 2].view(torch.int16).cpu().numpy().view(np.uint16)
+        exp = O.run_bf16(shape, bits, t, weights=w, separable=c["opts"].get("separable", -1) != 0)
+        return bool(np.array_equal(got, exp)), "bits"
+    b0 = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    b1 = torch.zeros_like(b0)
+    plan.run(b0, b1, t)
+    torch.cuda.synchronize()
+    got = (b0, b1)[t % 2].cpu().numpy()
+    exp = O.run(shape, a, t, weights=w) if c["bc"] == "reference" else O.run_bc(shape, a, t, c["bc"], weights=w)
+    if a.ndim == 1 and c["bc"] == "reference":
+        got, exp = got[:-1], exp[:-1]  # the host operator's copy-back omits the last element
+    if not np.isfinite(exp).all():
+        return True, "overflow"
+    integer = (not c["real_input"]) and c["taps"] == "default" and np.abs(exp).max() < 2.0 ** 53
+    if integer:
+        return bool(np.array_equal(got, exp)), "exact"
+    den = max(np.abs(exp).max(), 1e-300)
+    return bool(np.abs(got - exp).max() / den < 1e-12), "rel"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cases", type=int, default=400)
+    ap.add_argument("--seconds", type=float, default=240.0)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    t0 = time.time()
+    bad = 0
+    done = 0
+    kinds = {}
+    for i in range(args.cases):
+        if time.time() - t0 > args.seconds:
+            break
+        c = draw_case(rng)
+        ok, how = run_case(c, rng)
+        kinds[how] = kinds.get(how, 0) + 1
+        done += 1
+        if not ok:
+            bad += 1
+            print("MISMATCH", c, flush=True)
+        if done % 50 == 0:
+            print(f"... {done} cases, {bad} mismatches, {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz_parity: {done} cases ({kinds}), {bad} mismatches, seed {args.seed}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
