@@ -856,6 +856,74 @@ def test_full_size_constant_field_and_windows(L, O, shape, dims):
     assert torch.equal(fused, two)
 
 
+@pytest.mark.parametrize("shape,dims,dtype", [
+    ("star2d1r", (49152, 49152), "f64"),        # 2.4e9 points, 19.3 GB per buffer: element indices exceed 2^31
+    ("star3d1r", (1600, 1200, 1280), "f64"),    # 2.5e9 points, 19.7 GB per buffer
+    ("box3d1r", (2400, 1280, 1536), "bf16"),    # 4.7e9 points, 9.5 GB per buffer: byte offsets exceed 2^32
+    ("1d1r", (2 ** 31 - 4096,), "f64"),         # 17.2 GB per buffer: byte offsets exceed 2^32, indices reach 2^31
+])
+def test_grids_beyond_32_bit_indexing(L, O, shape, dims, dtype):
+    """288 GB of HBM allow grids whose element counts and byte offsets do not fit 32 bits: sampled windows of one
+    single sweep and of one fused launch near the far end of the array, exact against the oracle."""
+    import torch
+
+    plan = L.Plan(shape, dims, dtype=dtype)
+    ps = plan.padded_shape
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float64
+    src = torch.empty(ps, dtype=tdt, device="cuda")
+    # value = (linear index mod 97) without materialising a 64-bit index tensor: row pattern + per-row offset
+    h = L.ops.halo(shape)
+    if len(dims) == 1:
+        step = 1 << 24
+        for lo in range(0, ps[0], step):
+            hi = min(lo + step, ps[0])
+            src[lo:hi] = (torch.arange(lo, hi, device="cuda", dtype=torch.int64) % 97).to(tdt)
+    else:
+        inner = torch.arange(ps[-1], device="cuda", dtype=torch.int64)
+        flat = src.view(-1, ps[-1])
+        rows = flat.shape[0]
+        blk = 1 << 14
+        for lo in range(0, rows, blk):
+            hi = min(lo + blk, rows)
+            r = torch.arange(lo, hi, device="cuda", dtype=torch.int64)[:, None]
+            flat[lo:hi] = ((r * 31 + inner[None, :] * 7) % 97).to(tdt)
+    dst = torch.zeros_like(src)
+    w = O.effective_weights(shape)  # integer taps on integers 0..96: every partial sum is exact, whatever the order
+    win = {1: (5000,), 2: (70, 140), 3: (6, 20, 136)}[len(dims)]
+    corners = [tuple(0 for _ in dims), tuple(d - wd for d, wd in zip(dims, win)),
+               tuple((d - wd) // 2 for d, wd in zip(dims, win))]
+
+    def window(t, c, reach):
+        sl = tuple(slice(ci, ci + wd + 2 * k) for ci, wd, k in zip(c, win, h))
+        x = t[sl].contiguous()
+        return x.view(torch.int16).cpu().numpy().view(np.uint16) if dtype == "bf16" else x.cpu().numpy()
+
+    def interior(x, reach):
+        return x[tuple(slice(k + reach, x.shape[i] - k - reach) for i, k in enumerate(h))]
+
+    radius = {1: 4, 2: 3, 3: 1}[len(dims)]
+    plan.step(src, dst)
+    torch.cuda.synchronize()
+    for c in corners:
+        sub = window(src, c, 0)
+        exp = O.run_bf16(shape, sub, 1, weights=w) if dtype == "bf16" else O.step(shape, sub, w)
+        assert np.array_equal(interior(window(dst, c, 0), 0), interior(exp, 0)), f"single sweep, window at {c}"
+    # one fused launch (2 applications, 8 in 1D): windows well inside the grid see no boundary effect, so K sweeps of
+    # the oracle on the window agree on its core (reach = radius x (K - 1) cells from the window's rim)
+    k_apps = plan.get_option("steps_per_launch")
+    assert k_apps >= 2
+    dst.copy_(src)
+    plan.stepk(src, dst)
+    torch.cuda.synchronize()
+    c = corners[2]
+    sub = window(src, c, 0)
+    exp = O.run_bf16(shape, sub, k_apps, weights=w) if dtype == "bf16" else O.run(shape, sub, k_apps, weights=w)
+    reach = radius * (k_apps - 1)
+    got = interior(window(dst, c, 0), reach)
+    want = interior(exp, reach)
+    assert np.array_equal(got, want)
+
+
 def test_full_size_bf16_box3d1r_768(L, O):
     """BASELINE.json configs[4] at full size: box3d1r 768^3 in bf16 (constant-field identities that are exact in
     bf16, and sampled windows of a random field compared bit-for-bit with the bf16 oracle)."""
