@@ -18,7 +18,8 @@ single-GPU kernels)::
 * On the launch that exhausts the ghost zone the two own boundary strips are swept first, their exchange is posted
   (it runs on the process group's own stream) and the interior is swept while the messages are in flight.
 * A rank at a global edge has no ghost rows there: its pad rows are the global halo and keep the reference's
-  semantics untouched (never written: the caller's input halo at even time levels, zeros at odd ones).
+  semantics untouched (never written: the caller's input halo at even time levels, zeros at odd ones, SURVEY B2);
+  ``boundary="dirichlet"`` keeps the caller's halo at every level instead.
 * Fused launches (``Plan.stepk_region``: 2 applications in 2D / 3D, 8 in 1D) are used exactly like in the
   single-GPU driver: both physical buffers then carry the level-0 halo ring, tails are single sweeps.
 
@@ -109,10 +110,12 @@ def slab_layout(shape, global_dims: Sequence[int], world_size: int, rank: int, m
 class HipStepper:
     """Product stepper: the HIP engine on the local array (own rows + ghost rows)."""
 
-    def __init__(self, layout: SlabLayout, params=None, weights=None, dtype="f64"):
+    def __init__(self, layout: SlabLayout, params=None, weights=None, dtype="f64", boundary="reference"):
         self.plan = ops.Plan(layout.shape, layout.local_dims, params, dtype=dtype)
         if weights is not None:
             self.plan.set_weights(weights)
+        if boundary != "reference":
+            self.plan.set_boundary(boundary)  # fused launches: intermediate halo cells keep the source's values
         # launches go to the stream that is current when the driver is built (looked up once: at 8 GPUs a launch is
         # ~100 us of GPU time, so per-call host work matters)
         self.stream = int(torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else 0
@@ -139,7 +142,10 @@ class SlabDriver:
     def __init__(self, shape, global_dims: Sequence[int], group=None, device=None, params=None, weights=None,
                  stepper_factory: Callable[[SlabLayout], object] | None = None, overlap: bool = True,
                  exchange_every: int | None = None, fused: bool | None = None, boundary_rows: int | None = None,
-                 dtype="f64"):
+                 dtype="f64", boundary: str = "reference"):
+        if boundary not in ("reference", "dirichlet"):
+            raise ValueError("the slab driver implements the reference and the Dirichlet boundary")
+        self.dirichlet = boundary == "dirichlet"
         self.group = group
         self._host_side_p2p = dist.is_initialized() and dist.get_backend(group) != "nccl"
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -156,7 +162,7 @@ class SlabDriver:
         self.dtype = ops.dtype_id(dtype)
         self.torch_dtype = torch.bfloat16 if self.dtype == ops.DTYPES["bf16"] else torch.float64
         self._make_stepper = stepper_factory or (
-            lambda lay: HipStepper(lay, params=params, weights=weights, dtype=self.dtype))
+            lambda lay: HipStepper(lay, params=params, weights=weights, dtype=self.dtype, boundary=boundary))
         # thinnest slab of the decomposition bounds the ghost depth (neighbours supply ghost rows from own rows)
         thinnest = min(slab_layout(sid, global_dims, self.world_size, r).own for r in range(self.world_size))
         if exchange_every is None:
@@ -294,7 +300,9 @@ class SlabDriver:
             sweep = getattr(self.stepper, "stepk_region", None) or self.stepper.step2_region
         else:
             sweep = self.stepper.step_region
-        if self.fused or fused:
+        if self.dirichlet:
+            self._set_ring(dst_i, "input", src_i)  # fixed boundary: every level carries the caller's halo ring
+        elif self.fused or fused:
             # fused launches need the level-0 ring in both buffers; a single sweep from an even level writes the
             # odd level, whose ring is 0; from an odd level it writes an even one (ring = input)
             even = self.steps_done % 2 == 0

@@ -1013,7 +1013,7 @@ def test_reference_harness_self_check_on_this_engine(L, dim, args):
 # multi-rank slabs with the REAL HIP stepper: three ranks share this one GPU and exchange ghost zones over gloo
 # (RCCL itself needs one GPU per rank; everything else of the N > 1 product path runs here)
 # ---------------------------------------------------------------------------------------------------------
-def _slab_rank(rank, world, port, shape, dims, times, every, dtype, q):
+def _slab_rank(rank, world, port, shape, dims, times, every, dtype, q, boundary="reference"):
     import torch
     import torch.distributed as dist
 
@@ -1025,7 +1025,7 @@ def _slab_rank(rank, world, port, shape, dims, times, every, dtype, q):
         from oracle import oracle as O
 
         a = O.reference_input(shape, dims)
-        drv = slab.SlabDriver(shape, dims, device="cuda:0", exchange_every=every, dtype=dtype)
+        drv = slab.SlabDriver(shape, dims, device="cuda:0", exchange_every=every, dtype=dtype, boundary=boundary)
         if dtype == "bf16":
             bits = O.to_bf16(a)
             drv.load_global(torch.from_numpy(bits.view(np.int16)).view(torch.bfloat16))
@@ -1082,6 +1082,36 @@ def test_three_rank_slabs_on_one_gpu_equal_single_rank(L, O, shape, dims, times,
             assert rel_err(got, exp) < 1e-13
     assert fused  # 2D and 3D, fp64 and bf16: two applications per launch
     assert ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * (8 if len(dims) == 1 else 2) * every
+
+
+@pytest.mark.parametrize("shape,dims,times", [("star2d1r", (384, 256), 9), ("star3d1r", (24, 20, 64), 7),
+                                              ("1d1r", (30000,), 21)])
+def test_three_rank_dirichlet_slabs_on_one_gpu(L, O, shape, dims, times):
+    """The Dirichlet option across slabs with the real HIP stepper (fused launches keep the caller's halo)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_slab_rank, args=(r, world, port, shape, dims, times, 2, "f64", q, "dirichlet"))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    got, fused, ghost = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    exp = O.run_bc(shape, O.reference_input(shape, dims), times, "dirichlet")
+    assert fused
+    if np.abs(exp).max() < 2.0 ** 53:
+        assert np.array_equal(got, exp)
+    else:
+        assert rel_err(got, exp) < 1e-13
 
 
 def test_rccl_backend_initialises_and_slab_driver_runs_under_it(L, O):

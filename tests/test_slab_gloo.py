@@ -20,9 +20,10 @@ if ROOT not in sys.path:
 class OracleStepper:
     """CPU stand-in for HipStepper (tests only)."""
 
-    def __init__(self, layout, weights, wants_fused=True):
+    def __init__(self, layout, weights, wants_fused=True, dirichlet=False):
         from lorastencil_amd import ops
 
+        self.dirichlet = dirichlet
         self.shape = layout.shape
         self.w = weights
         self.h = ops.halo(layout.shape)
@@ -42,7 +43,7 @@ class OracleStepper:
         cur = s
         for level in range(1, self.apps_per_launch + 1):
             cur = O.step(self.shape, cur, self.w)  # zeros outside the local interior
-            if level % 2 == 0 and level < self.apps_per_launch:
+            if (level % 2 == 0 or self.dirichlet) and level < self.apps_per_launch:
                 for d, k in enumerate(self.h):
                     for side in (slice(0, k), slice(-k, None)):
                         idx = (slice(None),) * d + (side,)
@@ -150,7 +151,7 @@ def test_bf16_slabs_equal_single_rank(engine_built):
     assert np.array_equal(got, O.run_bf16(shape, bits, times))
 
 
-def _worker(rank, world, port, shape, dims, times, overlap, q, fused=None, exchange_every=None):
+def _worker(rank, world, port, shape, dims, times, overlap, q, fused=None, exchange_every=None, boundary="reference"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -161,8 +162,9 @@ def _worker(rank, world, port, shape, dims, times, overlap, q, fused=None, excha
         a = O.reference_input(shape, dims)
         w = O.effective_weights(shape)
         drv = slab.SlabDriver(shape, dims, device="cpu", overlap=overlap, boundary_rows=4, fused=fused,
-                              exchange_every=exchange_every,
-                              stepper_factory=lambda lay: OracleStepper(lay, w, wants_fused=fused is not False))
+                              exchange_every=exchange_every, boundary=boundary,
+                              stepper_factory=lambda lay: OracleStepper(lay, w, wants_fused=fused is not False,
+                                                                        dirichlet=boundary == "dirichlet"))
         drv.load_global(a)
         # split the run in two calls: the driver must be resumable at any time level
         drv.run(times // 2)
@@ -180,11 +182,13 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def run_slabs(world, shape, dims, times, overlap=True, fused=None, exchange_every=None, info=False):
+def run_slabs(world, shape, dims, times, overlap=True, fused=None, exchange_every=None, info=False,
+              boundary="reference"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, dims, times, overlap, q, fused, exchange_every))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, dims, times, overlap, q, fused, exchange_every,
+                                               boundary))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -243,6 +247,20 @@ def test_ghost_zone_schedules_equal_single_rank(engine_built, world, shape, dims
     assert was_fused == (fused is None)
     if was_fused and times // 2 >= apps:  # the run is split in two calls of times // 2 and the rest
         assert calls["step2"] > 0
+
+
+@pytest.mark.parametrize("world,shape,dims,times,fused", [
+    (2, "star2d1r", (128, 64), 7, None), (3, "box3d1r", (30, 6, 8), 6, None), (2, "1d1r", (8192,), 21, None),
+    (2, "star2d3r", (128, 32), 5, False),
+])
+def test_dirichlet_slabs_equal_single_rank(engine_built, world, shape, dims, times, fused):
+    """boundary="dirichlet": the caller's halo ring is kept at every time level, also inside fused launches."""
+    from oracle import oracle as O
+
+    a = O.reference_input(shape, dims)
+    expect = O.run_bc(shape, a, times, "dirichlet")
+    got = run_slabs(world, shape, dims, times, fused=fused, exchange_every=2, boundary="dirichlet")
+    assert np.array_equal(got, expect)
 
 
 def test_slabs_without_overlap_path(engine_built):
