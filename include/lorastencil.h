@@ -170,7 +170,7 @@ int lora_set_default_boundary(int boundary);
  *   steps_per_launch  0 auto / 1 / 2 (1D also 4, 8) : applications per launch in lora_plan_run (temporal fusion;
  *                     default 2 for every tiled 2D and 3D plan, fp64 and bf16, and 8 in 1D)
  *   rows_per_thread, panel_width, nt_store, fused_rows, persistent      2D tile shape / block->tile map / stores
- *   lowrank_valu      -1 auto / 0 / 1 / 2 (plain pyramid form) : low-rank evaluation inside the fused 2D kernel (summation order changes:
+ *   lowrank_valu      -1 auto / 0 / 1 / 2, 3 (plain / symmetric pyramid form) : low-rank evaluation inside the fused 2D kernel (summation order changes:
  *                     identical while values are exact integers, ~1 ulp afterwards)
  *   z_chunk, fused_z_chunk             3D output planes per workgroup (single-sweep / fused kernels; 0 = auto)
  *   separable         -1 auto / 0     bf16: exactly separable taps as x/y/z passes (changes the fp32 summation

@@ -208,7 +208,11 @@ void plan_refresh(Plan &p) {
                 for (int t = 0; t < 3 && sym; ++t)
                     for (int e = 0; e < 3; ++e)
                         if (lr.v[t][e] != lr.v[t][6 - e]) sym = false;
-                if (sym) p.fused_eval = 5;
+                if (sym) {
+                    p.fused_eval = 5;
+                    // the reference table's middle factor (0, 1, 0, -1, 0, 1, 0): zero taps skipped at compile time
+                    if (p.lowrank_valu != 3 && lr.u[1][2] == 0.0 && lr.u[1][4] == 0.0 && lr.v[1][2] == 0.0) p.fused_eval = 6;
+                }
             }
         }
         p.kernel_name = p.generic ? kernel_name_generic(p)
@@ -449,7 +453,7 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.use_graph = value;
     } else if (!std::strcmp(key, "lowrank_valu")) {
-        if (value < -1 || value > 2) return LORA_EINVAL;
+        if (value < -1 || value > 3) return LORA_EINVAL;  // 2 / 3: plain / symmetric pyramid form (A/B timing)
         p.lowrank_valu = value;
     } else if (!std::strcmp(key, "separable")) {
         if (value < -1 || value > 1) return LORA_EINVAL;

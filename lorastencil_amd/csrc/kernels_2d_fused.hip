@@ -45,7 +45,10 @@ constexpr int kInChunks = kInW / 2;   // 16-byte chunks per staged row
 // EVAL_LR_PYRAMID_SYM: the pyramid form for mirror-symmetric horizontal profiles (v_t[dx] = v_t[6-dx], true for every
 // table the pyramid factoriser accepts): the mirrored taps of a row are added once (3 adds per column) and shared by
 // the three terms -- 12 instead of 15 operations per column for the horizontal pass, 54 instead of 60 per input row.
-enum { EVAL_LR_DIAMOND = 3, EVAL_LR_PYRAMID = 4, EVAL_LR_PYRAMID_SYM = 5 };
+// EVAL_LR_PYRAMID_SYM_GAP: additionally the middle term vanishes next to its centre (u_1[2] = u_1[4] = v_1[2] = 0), as in
+// the reference's own table, whose second factor is (0, 1, 0, -1, 0, 1, 0) (2d/main.cu:151-167 through 2d/gpu.cu:280-350):
+// those taps are skipped at compile time, 48 operations per input row.
+enum { EVAL_LR_DIAMOND = 3, EVAL_LR_PYRAMID = 4, EVAL_LR_PYRAMID_SYM = 5, EVAL_LR_PYRAMID_SYM_GAP = 6 };
 
 struct LowRankTaps {
     double u[3][7];  // vertical profiles
@@ -71,7 +74,8 @@ __device__ __forceinline__ void apply_row(const int j, const double (&win)[8], d
                 }
             }
         }
-    } else if constexpr (EVAL == EVAL_LR_PYRAMID_SYM) {
+    } else if constexpr (EVAL == EVAL_LR_PYRAMID_SYM || EVAL == EVAL_LR_PYRAMID_SYM_GAP) {
+        constexpr bool GAP = EVAL == EVAL_LR_PYRAMID_SYM_GAP;
         // s[k] = win[k] + win[6 - k] for column 0, win[k + 1] + win[7 - k] for column 1 (k = 0..2); centre taps as they are
         double s0[3], s1[3];
 #pragma unroll
@@ -85,13 +89,14 @@ __device__ __forceinline__ void apply_row(const int j, const double (&win)[8], d
             double h0 = F.v[t][3] * win[3], h1 = F.v[t][3] * win[4];
 #pragma unroll
             for (int k = 2; k >= lo; --k) {
+                if (GAP && t == 1 && k == 2) continue;
                 h0 = fma(F.v[t][k], s0[k], h0);
                 h1 = fma(F.v[t][k], s1[k], h1);
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 const int dy = j - r;
-                if (dy >= lo && dy <= hi) {
+                if (dy >= lo && dy <= hi && !(GAP && t == 1 && (dy == 2 || dy == 4))) {
                     acc0[r] = fma(F.u[t][dy], h0, acc0[r]);
                     acc1[r] = fma(F.u[t][dy], h1, acc1[r]);
                 }
@@ -385,6 +390,7 @@ hipError_t launch_2d_fused2(const Plan &p, const double *in, double *out, int be
     if (p.fused_eval == EVAL_LR_DIAMOND) return launch_fused2_t<EVAL_LR_DIAMOND, R1>(p, in, out, begin, end, s); \
     if (p.fused_eval == EVAL_LR_PYRAMID) return launch_fused2_t<EVAL_LR_PYRAMID, R1>(p, in, out, begin, end, s); \
     if (p.fused_eval == EVAL_LR_PYRAMID_SYM) return launch_fused2_t<EVAL_LR_PYRAMID_SYM, R1>(p, in, out, begin, end, s); \
+    if (p.fused_eval == EVAL_LR_PYRAMID_SYM_GAP) return launch_fused2_t<EVAL_LR_PYRAMID_SYM_GAP, R1>(p, in, out, begin, end, s); \
     switch (p.tapset) {                                                                 \
         case TAPS2D_DIAMOND:                                                            \
             return launch_fused2_t<TAPS2D_DIAMOND, R1>(p, in, out, begin, end, s);     \

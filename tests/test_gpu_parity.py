@@ -245,7 +245,7 @@ def test_fused_lowrank_evaluation_on_the_vector_pipe(L, O):
     then vertical scatter) when the factors fit; forcing the direct taps must give the same grid."""
     import torch
 
-    for shape, expect_eval in (("star2d1r", 3), ("box2d3r", 5), ("box2d1r", 5), ("star2d3r", 1)):
+    for shape, expect_eval in (("star2d1r", 3), ("box2d3r", 6), ("box2d1r", 6), ("star2d3r", 1)):
         dims = (150, 380)
         a = O.reference_input(shape, dims)
         exp = O.run(shape, a, 4)
@@ -254,6 +254,7 @@ def test_fused_lowrank_evaluation_on_the_vector_pipe(L, O):
         assert np.array_equal(plan_run(L, shape, a, 4), exp), shape
         assert np.array_equal(plan_run(L, shape, a, 4, options={"lowrank_valu": 0}), exp), shape
         assert np.array_equal(plan_run(L, shape, a, 4, options={"lowrank_valu": 2}), exp), shape  # plain pyramid form
+        assert np.array_equal(plan_run(L, shape, a, 4, options={"lowrank_valu": 3}), exp), shape  # symmetric, no gap
         off = L.Plan(shape, dims).set_option("lowrank_valu", 0)
         assert off.get_option("fused_eval") == {"star2d1r": 0, "box2d3r": 2, "box2d1r": 2, "star2d3r": 1}[shape]
     # scaled star2d1r taps keep the form; real-valued data within rounding of the oracle
