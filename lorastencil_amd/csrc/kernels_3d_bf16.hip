@@ -492,7 +492,7 @@ constexpr int kFusedChunks = kFusedLdsW / 8;       // 18 pieces of 16 bytes per 
 // PIPE: both tiles double-buffered (39 KB) and level 2 runs one plane behind level 1 -- iteration p sweeps input
 // plane p from A[p & 1] AND level-1 plane p-2 from B[(p-1) & 1] back to back, then publishes level-1 plane p-1 in
 // B[p & 1] and refills A[(p+1) & 1]: ONE barrier per plane instead of two, at the price of one more iteration.
-template <int TAPSET, int RY, bool PIPE>
+template <int TAPSET, int RY, bool PIPE, bool DIRICHLET>
 __global__ __launch_bounds__(256, 3) void stencil3d_bf16_fused2_kernel(const Args3Dh a, const Taps27f W) {
     constexpr int MH = 8 * RY;
     constexpr int OH = MH - 2;
@@ -602,7 +602,8 @@ __global__ __launch_bounds__(256, 3) void stencil3d_bf16_fused2_kernel(const Arg
             u32x2 v;
             v.x = in ? pack_bf16(acc1[s][r][0].x, acc1[s][r][0].y) : 0u;
             v.y = in ? pack_bf16(acc1[s][r][1].x, acc1[s][r][1].y) : 0u;
-            if (a.dirichlet && !in) {  // fixed boundary: halo cells keep the source's value at every level
+            if (DIRICHLET && !in) {  // fixed boundary: halo cells keep the source's value at every level (template
+                                     // flag: as a run-time one it costs the reference path 9 VGPRs = one workgroup per CU)
                 const int pz = z1 + 1, pr = row1 + r + 2, pc = col + 4;
                 if (pz >= 0 && pz <= a.h + 1 && pr >= 0 && pr <= a.m + 3 && pc >= 0 && pc + 3 <= a.n + 7)
                     v = *reinterpret_cast<const u32x2 *>(a.in + (long) pz * a.plane + (long) pr * a.ld + pc);
@@ -698,10 +699,12 @@ hipError_t launch_bf16_fused2(const Plan &p, const void *in, void *out, int begi
     for (int k = 0; k < 27; ++k) w.w[k] = (float) p.w[k];
     if (TAPSET == TAPS3D_SEP)
         for (int k = 0; k < 9; ++k) w.w[k] = p.sep[k];
-    if (p.fused_pipeline)
-        hipLaunchKernelGGL((stencil3d_bf16_fused2_kernel<TAPSET, RY, true>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
+    if (a.dirichlet)
+        hipLaunchKernelGGL((stencil3d_bf16_fused2_kernel<TAPSET, RY, false, true>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
+    else if (p.fused_pipeline)
+        hipLaunchKernelGGL((stencil3d_bf16_fused2_kernel<TAPSET, RY, true, false>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
     else
-        hipLaunchKernelGGL((stencil3d_bf16_fused2_kernel<TAPSET, RY, false>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
+        hipLaunchKernelGGL((stencil3d_bf16_fused2_kernel<TAPSET, RY, false, false>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);
     return hipGetLastError();
 }
 
