@@ -54,11 +54,12 @@ def main():
     cases = [
         ("star2d1r", (16384, 16384), {"steps_per_launch": [2], "lowrank_valu": [0, 1], "fused_rows": [6, 8, 10]}),
         ("box2d3r", (8192, 8192), {"steps_per_launch": [2], "lowrank_valu": [0, 1], "fused_rows": [6, 8, 10]}),
-        ("star2d1r", (16384, 16384), {"rows_per_thread": [4, 8], "panel_width": [16, 32], "variant": [1]}),
+        ("star2d1r", (16384, 16384), {"steps_per_launch": [1], "rows_per_thread": [4, 8], "panel_width": [16, 32], "variant": [1]}),
         ("star2d1r", (16384, 16384), {"panel_width": [16, 32], "variant": [2]}),
-        ("box2d3r", (8192, 8192), {"rows_per_thread": [4, 8], "panel_width": [8, 16, 32, 64], "variant": [1]}),
+        ("box2d3r", (8192, 8192), {"steps_per_launch": [1], "rows_per_thread": [4, 8], "panel_width": [8, 16, 32, 64], "variant": [1]}),
         ("box2d3r", (8192, 8192), {"panel_width": [16, 32], "variant": [2]}),
-        ("star2d3r", (16384, 16384), {"rows_per_thread": [4, 8], "panel_width": [16, 32], "variant": [1]}),
+        ("star2d3r", (16384, 16384), {"steps_per_launch": [1], "rows_per_thread": [4, 8], "panel_width": [16, 32], "variant": [1]}),
+        ("star2d3r", (16384, 16384), {"steps_per_launch": [2], "fused_rows": [6, 8, 10]}),
         ("star2d3r", (16384, 16384), {"panel_width": [32], "variant": [2]}),
         ("star3d1r", (512, 512, 512), {"steps_per_launch": [1], "z_chunk": [4, 7, 16, 31, 64]}),
         ("box3d1r", (768, 768, 768), {"steps_per_launch": [1], "z_chunk": [7, 16, 31]}),
@@ -72,8 +73,8 @@ def main():
                                       "fused_z_chunk": [12, 16, 24, 32, 48, 64]}, "bf16"),
         ("box3d1r", (768, 768, 768), {"steps_per_launch": [2], "fused_pipeline": [0, 1]}, "bf16"),
         ("star3d1r", (768, 768, 768), {"steps_per_launch": [1, 2]}, "bf16"),
-        ("1d1r", (1048576,), {}),
-        ("1d1r", (1 << 28,), {}),
+        ("1d1r", (1048576,), {"steps_per_launch": [1, 2, 4, 8]}),
+        ("1d1r", (1 << 28,), {"steps_per_launch": [1, 2, 4, 8]}),
     ]
     for case in cases:
         shape, dims, grid = case[:3]
@@ -101,9 +102,11 @@ def main():
                 else:
                     plan.set_option(k, v)
             iters = 5 if args.quick else 20
-            spl = plan.get_option("steps_per_launch") if len(dims) >= 2 else 1
-            if spl == 2:
-                t = time_fn(lambda: plan.step2(src, dst), iters) / 2.0  # per application
+            spl = plan.get_option("steps_per_launch")
+            if plan.get_option("variant") == 2:
+                spl = 1  # the MFMA variant is a single-sweep kernel
+            if spl >= 2:
+                t = time_fn(lambda: plan.stepk(src, dst), iters) / spl  # per application
             else:
                 t = time_fn(lambda: plan.step(src, dst), iters)
             record(kind="sweep", shape=shape, dims=dims, dtype=dtype, options=dict(zip(keys, combo)),
