@@ -99,6 +99,18 @@ def cpu_baseline(shape, dims, budget_s):
     O.step(shape, np.ascontiguousarray(a1), w, out=o1, threads=1)
     el1 = time.perf_counter() - t1
     pts1 = n1 * inner
+    # the reference's OWN checker (oracle/_ref, built from its sources where they are available), same piece, 1 thread
+    ref_rate = None
+    try:
+        from oracle import ref as R
+
+        if R.available():
+            a1c = np.ascontiguousarray(a1)
+            t2 = time.perf_counter()
+            R.test_cpu(a1c, O.default_params(shape), o1)
+            ref_rate = round(pts1 / (time.perf_counter() - t2) / 1e9, 4)
+    except Exception:  # the _ref build is optional on the GPU box
+        ref_rate = None
     return {
         "value": round(val, 4),
         "unit": "GStencils/s",
@@ -107,6 +119,7 @@ def cpu_baseline(shape, dims, budget_s):
         "sample": f"{shape} sub-grid {'x'.join(str(d) for d in sdims)} of the {'x'.join(str(d) for d in dims)} "
                   f"workload, {reps} sweeps, OpenMP over rows, same taps/order as the reference's test_cpu",
         "value_1thread": round(pts1 / el1 / 1e9, 4),
+        "reference_test_cpu_1thread": ref_rate,  # kind "reference": the reference's test_cpu itself, single-threaded
         "host_cpus": os.cpu_count(),
     }
 
