@@ -284,7 +284,7 @@ def main():
                 "workload": f"{shape} {'x'.join(map(str, dims))} {'bf16' if bf16 else 'fp64'}, {K} sweeps (lorastencil_{len(dims)}d {shape} "
                             f"{' '.join(map(str, dims))} {K})",
                 "parallelism": (f"row-slabs x{world}, ghost {drv.layout.ghost} rows refreshed every "
-                                f"{drv.exchange_every} launches") if world > 1 else "single GPU",
+                                f"{drv.exchange_every} launches ({drv.exchange_mode})") if world > 1 else "single GPU",
                 "kernel": kernel,
                 "variant": {1: "direct", 2: "mfma"}.get(plan.get_option("variant"), "?"),
                 "normalised_taps": bool(normalised),

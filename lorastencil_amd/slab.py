@@ -32,6 +32,7 @@ inject one to exercise the decomposition, ghost-zone bookkeeping and exchange lo
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Callable, Sequence
 
@@ -107,6 +108,23 @@ def slab_layout(shape, global_dims: Sequence[int], world_size: int, rank: int, m
     return lay
 
 
+class _GatherWork:
+    """Completion handle of the all-gather form of the ghost exchange: wait() also scatters the neighbours' strips."""
+
+    def __init__(self, work, everyone, t, g, first, last, up, down):
+        self.work, self.everyone, self.t, self.g = work, everyone, t, g
+        self.first, self.last, self.up, self.down = first, last, up, down
+
+    def wait(self):
+        self.work.wait()
+        g = self.g
+        if self.up is not None:
+            self.t[self.first - g:self.first].copy_(self.everyone[self.up][g:2 * g])  # its bottom strip
+        if self.down is not None:
+            self.t[self.last:self.last + g].copy_(self.everyone[self.down][:g])       # its top strip
+        return True
+
+
 class HipStepper:
     """Product stepper: the HIP engine on the local array (own rows + ghost rows)."""
 
@@ -148,6 +166,10 @@ class SlabDriver:
         self.dirichlet = boundary == "dirichlet"
         self.group = group
         self._host_side_p2p = dist.is_initialized() and dist.get_backend(group) != "nccl"
+        self.exchange_mode = os.environ.get("LORA_SLAB_EXCHANGE", "p2p")  # "p2p" (default) or "allgather"
+        if self.exchange_mode not in ("p2p", "allgather"):
+            raise ValueError("LORA_SLAB_EXCHANGE must be p2p or allgather")
+        self._p2p_worked = False
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -273,20 +295,35 @@ class SlabDriver:
             torch.cuda.current_stream(t.device).synchronize()
         first = lay.halo0 + lay.ghost_top  # padded index of the first own row
         last = first + lay.own
-        opsl = []
-        if self.up is not None:
-            opsl.append(dist.P2POp(dist.isend, t[first:first + g], self.up, group=self.group))
-            opsl.append(dist.P2POp(dist.irecv, t[first - g:first], self.up, group=self.group))
-        if self.down is not None:
-            opsl.append(dist.P2POp(dist.isend, t[last - g:last], self.down, group=self.group))
-            opsl.append(dist.P2POp(dist.irecv, t[last:last + g], self.down, group=self.group))
-        return dist.batch_isend_irecv(opsl) if opsl else []
+        if self.exchange_mode == "p2p":
+            opsl = []
+            if self.up is not None:
+                opsl.append(dist.P2POp(dist.isend, t[first:first + g], self.up, group=self.group))
+                opsl.append(dist.P2POp(dist.irecv, t[first - g:first], self.up, group=self.group))
+            if self.down is not None:
+                opsl.append(dist.P2POp(dist.isend, t[last - g:last], self.down, group=self.group))
+                opsl.append(dist.P2POp(dist.irecv, t[last:last + g], self.down, group=self.group))
+            try:
+                return dist.batch_isend_irecv(opsl) if opsl else []
+            except RuntimeError:
+                if self._p2p_worked:
+                    raise
+                self.exchange_mode = "allgather"  # point-to-point refused by this backend / topology: collectives only
+        # Fallback (LORA_SLAB_EXCHANGE=allgather, or P2P refused on first use): every rank contributes its two boundary
+        # strips to one all-gather and picks its neighbours' -- N x the bytes of the P2P form, collectives only.
+        mine = torch.cat([t[first:first + g], t[last - g:last]], dim=0).contiguous()
+        flat = torch.empty((self.world_size * mine.shape[0],) + tuple(mine.shape[1:]), dtype=mine.dtype,
+                           device=mine.device)  # concatenated along dim 0 (the layout every backend accepts)
+        work = dist.all_gather_into_tensor(flat, mine, group=self.group, async_op=True)
+        everyone = flat.view((self.world_size,) + tuple(mine.shape))
+        return [_GatherWork(work, everyone, t, g, first, last, self.up, self.down)]
 
     def refresh_ghosts(self) -> None:
         """Blocking refresh of the ghost zones of the current buffer (used after loading device-generated data)."""
         if self.world_size > 1:
             for w in self._post_exchange(self.buf[self.cur]):
                 w.wait()
+            self._p2p_worked = True
         self.valid = self.layout.ghost
 
     # ---- one launch (1 or 2 applications) ---------------------------------------------------------------
@@ -328,6 +365,7 @@ class SlabDriver:
                     works = self._post_exchange(dst)
                 for w in works:
                     w.wait()
+                self._p2p_worked = True
                 self.valid = lay.ghost
             else:
                 lo = gt - (left if self.up is not None else 0)
