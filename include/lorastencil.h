@@ -206,6 +206,12 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
  * lora_plan_run uses an even number of these and finishes with single sweeps. */
 int lora_plan_stepk(lora_plan *plan, const void *d_in, void *d_out, void *stream);
 int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream);
+/* Halo cells of a padded device array (every cell outside the interior, any shape / dtype of the plan): copied from
+ * d_src (LORA_HALO_COPY), zeroed (LORA_HALO_ZERO) or wrapped from d_dst's own opposite interior edges
+ * (LORA_HALO_WRAP, periodic; LORA_EUNSUPPORTED if an extent is smaller than its halo).  What lora_plan_run uses for
+ * the boundary options and the fused launches' halo bookkeeping; exported for drivers that step themselves. */
+enum lora_halo_mode { LORA_HALO_COPY = 0, LORA_HALO_ZERO = 1, LORA_HALO_WRAP = 2 };
+int lora_plan_halo(lora_plan *plan, void *d_dst, const void *d_src, int mode, void *stream);
 /* The time-step driver (2d/gpu.cu:544-546): `times` applications ping-ponging between the two
  * buffers starting from d_buf0; the result is in buffer [times % 2].  The caller must have put
  * the padded input in d_buf0 and zeros in d_buf1 to get the reference semantics. */

@@ -92,6 +92,7 @@ SIGNATURES = {
     "lora_plan_step_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lora_plan_region_granularity": (ctypes.c_int, [_vp]),
     "lora_plan_step2": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
+    "lora_plan_halo": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),
     "lora_plan_stepk": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "lora_plan_step2_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lora_plan_stepk_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
@@ -119,6 +120,13 @@ def lib() -> ctypes.CDLL:
                 f"{LIB_PATH} is missing: build the HIP engine first (python -c 'import __graft_entry__ as g; "
                 f"g.build()' or make -C lorastencil_amd/csrc).  lorastencil_amd has no CPU fallback."
             )
+        # PyTorch-ROCm ships its own libamdhip64; if this library pulled in the system one first and torch loaded
+        # its copy afterwards, the process would hold two HIP runtimes and the second sees no device.  Import torch
+        # first wherever it is installed, so that both bind to the same runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header / library mismatch

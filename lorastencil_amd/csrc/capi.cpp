@@ -571,6 +571,25 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
     return LORA_OK;
 }
 
+int lora_plan_halo(lora_plan *plan, void *d_dst, const void *d_src, int mode, void *stream) {
+    if (!plan || !d_dst) return LORA_EINVAL;
+    if (mode != LORA_HALO_COPY && mode != LORA_HALO_ZERO && mode != LORA_HALO_WRAP) return LORA_EINVAL;
+    if (mode == LORA_HALO_COPY && (!d_src || d_src == d_dst)) return LORA_EINVAL;
+    const Plan &p = plan->p;
+    if (mode == LORA_HALO_WRAP) {
+        static const int h1[1] = {4}, h2[2] = {4, 4}, h3[3] = {1, 2, 4};
+        const int *h = p.ndim == 1 ? h1 : (p.ndim == 2 ? h2 : h3);
+        for (int d = 0; d < p.ndim; ++d)
+            if (p.dims[d] < h[d]) return LORA_EUNSUPPORTED;  // the wrap source would be a halo cell itself
+    }
+    const hipError_t e = lora::launch_halo(p, d_dst, d_src, mode, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        lora::set_last_error("halo kernel launch", e);
+        return LORA_EHIP;
+    }
+    return LORA_OK;
+}
+
 int lora_plan_step2(lora_plan *plan, const void *d_in, void *d_out, void *stream) {
     if (!plan) return LORA_EINVAL;
     return lora_plan_step2_region(plan, d_in, d_out, 0, plan->p.dims[0], stream);

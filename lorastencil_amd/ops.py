@@ -364,6 +364,12 @@ class Plan:
         check(_lib.lib().lora_plan_step2_region(self._h, _ptr(d_in), _ptr(d_out), int(begin), int(end),
                                                 _stream(stream)), "lora_plan_step2_region")
 
+    def halo(self, d_dst, mode: str, d_src=None, stream=None):
+        """Halo cells of a padded device array: "copy" (from d_src), "zero" or "wrap" (periodic, from d_dst itself)."""
+        m = {"copy": 0, "zero": 1, "wrap": 2}[mode]
+        check(_lib.lib().lora_plan_halo(self._h, _ptr(d_dst), _ptr(d_src) if d_src is not None else None, m,
+                                        _stream(stream)), "lora_plan_halo")
+
     def stepk(self, d_in, d_out, stream=None):
         """The plan's ``steps_per_launch`` applications in one launch (d_in must be an even time level)."""
         check(_lib.lib().lora_plan_stepk(self._h, _ptr(d_in), _ptr(d_out), _stream(stream)), "lora_plan_stepk")

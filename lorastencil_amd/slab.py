@@ -19,7 +19,9 @@ single-GPU kernels)::
   (it runs on the process group's own stream) and the interior is swept while the messages are in flight.
 * A rank at a global edge has no ghost rows there: its pad rows are the global halo and keep the reference's
   semantics untouched (never written: the caller's input halo at even time levels, zeros at odd ones, SURVEY B2);
-  ``boundary="dirichlet"`` keeps the caller's halo at every level instead.
+  ``boundary="dirichlet"`` keeps the caller's halo at every level instead; ``boundary="periodic"`` closes the slabs
+  into a ring (the first and the last rank exchange ghost rows too) and wraps the unsplit dimensions locally before
+  every sweep.
 * Fused launches (``Plan.stepk_region``: 2 applications in 2D / 3D, 8 in 1D) are used exactly like in the
   single-GPU driver: both physical buffers then carry the level-0 halo ring, tails are single sweeps.
 
@@ -54,6 +56,7 @@ class SlabLayout:
     begin: int  # first global interior index of the slab
     end: int  # one past the last
     ghost: int = 0  # ghost rows per neighbour side
+    ring: bool = False  # periodic along the split dimension: the first and the last slab are neighbours too
 
     @property
     def own(self) -> int:
@@ -61,11 +64,11 @@ class SlabLayout:
 
     @property
     def ghost_top(self) -> int:
-        return self.ghost if self.rank > 0 else 0
+        return self.ghost if (self.rank > 0 or self.ring) else 0
 
     @property
     def ghost_bottom(self) -> int:
-        return self.ghost if self.rank < self.world_size - 1 else 0
+        return self.ghost if (self.rank < self.world_size - 1 or self.ring) else 0
 
     @property
     def local_dims(self) -> tuple:
@@ -87,7 +90,7 @@ class SlabLayout:
 
 
 def slab_layout(shape, global_dims: Sequence[int], world_size: int, rank: int, multiple: int | None = None,
-                ghost: int = 0) -> SlabLayout:
+                ghost: int = 0, ring: bool = False) -> SlabLayout:
     """Balanced contiguous split; every slab boundary is a multiple of ``multiple`` (default: 32 rows in 2D,
     2 points in 1D, 1 plane in 3D)."""
     sid = ops.shape_id(shape)
@@ -102,7 +105,8 @@ def slab_layout(shape, global_dims: Sequence[int], world_size: int, rank: int, m
     start_u = rank * base + min(rank, extra)
     end_u = start_u + base + (1 if rank < extra else 0)
     begin, end = start_u * multiple, min(end_u * multiple, n0)
-    lay = SlabLayout(sid, tuple(int(d) for d in global_dims), world_size, rank, begin, end, ghost if world_size > 1 else 0)
+    lay = SlabLayout(sid, tuple(int(d) for d in global_dims), world_size, rank, begin, end,
+                     ghost if world_size > 1 else 0, ring and world_size > 1)
     if world_size > 1 and end - begin < max(lay.radius0, ghost):
         raise ValueError("slab thinner than its ghost zone")
     return lay
@@ -132,8 +136,10 @@ class HipStepper:
         self.plan = ops.Plan(layout.shape, layout.local_dims, params, dtype=dtype)
         if weights is not None:
             self.plan.set_weights(weights)
-        if boundary != "reference":
+        if boundary == "dirichlet":
             self.plan.set_boundary(boundary)  # fused launches: intermediate halo cells keep the source's values
+        if boundary == "periodic":
+            self.plan.set_option("steps_per_launch", 1)  # a fused launch would need the wrap of its inner levels
         # launches go to the stream that is current when the driver is built (looked up once: at 8 GPUs a launch is
         # ~100 us of GPU time, so per-call host work matters)
         self.stream = int(torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else 0
@@ -153,6 +159,11 @@ class HipStepper:
     def stepk_region(self, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
         self.plan.stepk_region(src.data_ptr(), dst.data_ptr(), begin, end, stream=self.stream)
 
+    def wrap(self, buf: torch.Tensor) -> None:
+        """Periodic halo of the LOCAL array (lora_plan_halo, wrap mode): right along the unsplit dimensions; along
+        the split one it only touches pad rows beyond the ghost zones, which nothing reads."""
+        self.plan.halo(buf.data_ptr(), "wrap", stream=self.stream)
+
 
 class SlabDriver:
     """Time-step driver of one rank's slab (reference driver semantics, 2d/gpu.cu:525-554, per slab)."""
@@ -161,9 +172,12 @@ class SlabDriver:
                  stepper_factory: Callable[[SlabLayout], object] | None = None, overlap: bool = True,
                  exchange_every: int | None = None, fused: bool | None = None, boundary_rows: int | None = None,
                  dtype="f64", boundary: str = "reference"):
-        if boundary not in ("reference", "dirichlet"):
-            raise ValueError("the slab driver implements the reference and the Dirichlet boundary")
+        if boundary not in ("reference", "dirichlet", "periodic"):
+            raise ValueError("boundary must be reference, dirichlet or periodic")
         self.dirichlet = boundary == "dirichlet"
+        self.periodic = boundary == "periodic"
+        if self.periodic:
+            fused = False  # single sweeps, each preceded by the wrap of the unsplit dimensions
         self.group = group
         self._host_side_p2p = dist.is_initialized() and dist.get_backend(group) != "nccl"
         self.exchange_mode = os.environ.get("LORA_SLAB_EXCHANGE", "p2p")  # "p2p" (default) or "allgather"
@@ -177,7 +191,7 @@ class SlabDriver:
         nd = len(global_dims)
         self.ndim = nd
         # a first, ghost-free layout tells how thick the slabs are; the ghost depth is then fitted to them
-        probe = slab_layout(sid, global_dims, self.world_size, self.rank)
+        probe = slab_layout(sid, global_dims, self.world_size, self.rank, ring=self.periodic)
         radius = probe.radius0
         if fused is None:
             fused = True  # refined below by what the stepper supports
@@ -196,7 +210,7 @@ class SlabDriver:
             e = max(1, min(exchange_every, thinnest // need if self.world_size > 1 else exchange_every))
             if self.world_size > 1 and thinnest < need:
                 continue
-            layout = slab_layout(sid, global_dims, self.world_size, self.rank, ghost=need * e)
+            layout = slab_layout(sid, global_dims, self.world_size, self.rank, ghost=need * e, ring=self.periodic)
             stepper = self._make_stepper(layout)
             if apps > 1:
                 has = hasattr(stepper, "stepk_region") or hasattr(stepper, "step2_region")
@@ -220,6 +234,9 @@ class SlabDriver:
             self.strip += self.strip & 1  # 1D regions start on even points
         self.up = self.rank - 1 if self.rank > 0 else None  # neighbour owning smaller indices
         self.down = self.rank + 1 if self.rank < self.world_size - 1 else None
+        if self.periodic and self.world_size > 1:  # a ring: the first and the last slab are neighbours
+            self.up = (self.rank - 1) % self.world_size
+            self.down = (self.rank + 1) % self.world_size
         self.steps_done = 0
         self.cur = 0  # physical buffer holding the current time level
         self.valid = layout.ghost  # ghost rows per side that hold the current time level
@@ -230,9 +247,16 @@ class SlabDriver:
         """buffer 0 <- this rank's rows of the global padded input (ghost rows and pads included), buffer 1 <- 0."""
         lay = self.layout
         h0 = lay.halo0
-        lo = lay.begin - lay.ghost_top
-        hi = lay.end + lay.ghost_bottom + 2 * h0
-        part = global_padded[lo:hi]
+        if lay.ring:
+            # own rows + ghost rows taken modulo the global extent; the pad rows beyond them are never read
+            n0 = lay.global_dims[0]
+            rows = (np.arange(lay.begin - lay.ghost_top - h0, lay.end + lay.ghost_bottom + h0) % n0) + h0
+            part = global_padded[torch.from_numpy(rows)] if isinstance(global_padded, torch.Tensor) \
+                else np.ascontiguousarray(np.asarray(global_padded)[rows])
+        else:
+            lo = lay.begin - lay.ghost_top
+            hi = lay.end + lay.ghost_bottom + 2 * h0
+            part = global_padded[lo:hi]
         if isinstance(part, np.ndarray):
             part = torch.from_numpy(np.ascontiguousarray(part))
         self.buf[0].copy_(part.to(self.device))
@@ -256,9 +280,13 @@ class SlabDriver:
         edge ranks; left/right halos travel with the rows).  Returns a CPU tensor there, None elsewhere."""
         lay = self.layout
         h0 = lay.halo0
+        if self.periodic:
+            self.stepper.wrap(self.buf[self.cur])  # the result is a consistent periodic array (like lora_plan_run)
         cur = self.result()
-        lo = 0 if self.up is None else h0 + lay.ghost_top
-        hi = cur.shape[0] if self.down is None else h0 + lay.ghost_top + lay.own
+        edge_top = self.up is None or (self.periodic and self.rank == 0)
+        edge_bottom = self.down is None or (self.periodic and self.rank == self.world_size - 1)
+        lo = h0 + lay.ghost_top - (h0 if edge_top else 0)
+        hi = h0 + lay.ghost_top + lay.own + (h0 if edge_bottom else 0)
         piece = cur[lo:hi].cpu()
         if self.world_size == 1:
             return piece
@@ -266,7 +294,12 @@ class SlabDriver:
         dist.gather_object(piece, pieces, dst=dst_rank, group=self.group)
         if self.rank != dst_rank:
             return None
-        return torch.cat(pieces, dim=0)
+        full = torch.cat(pieces, dim=0)
+        if self.periodic:  # pad rows of the split dimension = the opposite interior edge
+            n0 = lay.global_dims[0]
+            full[:h0] = full[n0:n0 + h0].clone()
+            full[h0 + n0:] = full[h0:2 * h0].clone()
+        return full
 
     # ---- halo-ring bookkeeping of the fused path -----------------------------------------------------
     def _set_ring(self, b: int, what: str, src: int) -> None:
@@ -296,13 +329,16 @@ class SlabDriver:
         first = lay.halo0 + lay.ghost_top  # padded index of the first own row
         last = first + lay.own
         if self.exchange_mode == "p2p":
+            # order: in a ring of two both neighbours are the same peer, and backends match the k-th send to a peer
+            # with its k-th receive from us -- our top strip must meet ITS bottom ghost zone
             opsl = []
             if self.up is not None:
                 opsl.append(dist.P2POp(dist.isend, t[first:first + g], self.up, group=self.group))
-                opsl.append(dist.P2POp(dist.irecv, t[first - g:first], self.up, group=self.group))
             if self.down is not None:
-                opsl.append(dist.P2POp(dist.isend, t[last - g:last], self.down, group=self.group))
                 opsl.append(dist.P2POp(dist.irecv, t[last:last + g], self.down, group=self.group))
+                opsl.append(dist.P2POp(dist.isend, t[last - g:last], self.down, group=self.group))
+            if self.up is not None:
+                opsl.append(dist.P2POp(dist.irecv, t[first - g:first], self.up, group=self.group))
             try:
                 return dist.batch_isend_irecv(opsl) if opsl else []
             except RuntimeError:
@@ -337,7 +373,9 @@ class SlabDriver:
             sweep = getattr(self.stepper, "stepk_region", None) or self.stepper.step2_region
         else:
             sweep = self.stepper.step_region
-        if self.dirichlet:
+        if self.periodic:
+            self.stepper.wrap(src)  # x / y (and, on one rank, the split dimension too): halo = opposite interior edge
+        elif self.dirichlet:
             self._set_ring(dst_i, "input", src_i)  # fixed boundary: every level carries the caller's halo ring
         elif self.fused or fused:
             # fused launches need the level-0 ring in both buffers; a single sweep from an even level writes the

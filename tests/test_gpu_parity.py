@@ -677,6 +677,38 @@ def test_boundary_condition_options(L, O, shape, dims, bc):
             assert rel_err(got, exp) < 1e-13
 
 
+def test_plan_halo_modes(L, O):
+    """lora_plan_halo: copy / zero / wrap of every cell outside the interior, any shape, fp64 and bf16."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    for shape, dims, dtype in (("1d1r", (37,), "f64"), ("star2d1r", (9, 14), "f64"), ("box3d1r", (5, 6, 16), "f64"),
+                               ("box3d1r", (5, 6, 16), "bf16")):
+        h = L.ops.halo(shape)
+        ps = O.padded_shape(shape, dims)
+        a = rng.integers(1, 90, ps).astype(np.float64)
+        b = rng.integers(1, 90, ps).astype(np.float64)
+        tdt = torch.bfloat16 if dtype == "bf16" else torch.float64
+        plan = L.Plan(shape, dims, dtype=dtype)
+        inner = tuple(slice(k, -k) for k in h)
+        ta, tb = torch.from_numpy(a).to(tdt).cuda(), torch.from_numpy(b).to(tdt).cuda()
+        plan.halo(tb, "copy", ta)
+        torch.cuda.synchronize()
+        exp = a.copy()
+        exp[inner] = b[inner]
+        assert np.array_equal(tb.double().cpu().numpy(), exp), (shape, "copy")
+        plan.halo(tb, "zero")
+        torch.cuda.synchronize()
+        exp = np.zeros_like(a)
+        exp[inner] = b[inner]
+        assert np.array_equal(tb.double().cpu().numpy(), exp), (shape, "zero")
+        plan.halo(tb, "wrap")
+        torch.cuda.synchronize()
+        assert np.array_equal(tb.double().cpu().numpy(), np.pad(b[inner], [(k, k) for k in h], mode="wrap")), (shape, "wrap")
+    with pytest.raises(L.LoraError):
+        L.Plan("star2d1r", (2, 64)).halo(torch.zeros((10, 72), dtype=torch.float64, device="cuda"), "wrap")
+
+
 def test_boundary_condition_bf16_and_validation(L, O):
     import torch
 
@@ -1085,10 +1117,12 @@ def test_three_rank_slabs_on_one_gpu_equal_single_rank(L, O, shape, dims, times,
     assert ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * (8 if len(dims) == 1 else 2) * every
 
 
+@pytest.mark.parametrize("boundary", ["dirichlet", "periodic"])
 @pytest.mark.parametrize("shape,dims,times", [("star2d1r", (384, 256), 9), ("star3d1r", (24, 20, 64), 7),
                                               ("1d1r", (30000,), 21)])
-def test_three_rank_dirichlet_slabs_on_one_gpu(L, O, shape, dims, times):
-    """The Dirichlet option across slabs with the real HIP stepper (fused launches keep the caller's halo)."""
+def test_three_rank_dirichlet_slabs_on_one_gpu(L, O, shape, dims, times, boundary):
+    """The Dirichlet option (fused launches keep the caller's halo) and the periodic one (a ring of slabs, single
+    sweeps after a wrap of the unsplit dimensions) across slabs with the real HIP stepper."""
     import socket
 
     import torch.multiprocessing as mp
@@ -1099,7 +1133,7 @@ def test_three_rank_dirichlet_slabs_on_one_gpu(L, O, shape, dims, times):
     world = 3
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_slab_rank, args=(r, world, port, shape, dims, times, 2, "f64", q, "dirichlet"))
+    procs = [ctx.Process(target=_slab_rank, args=(r, world, port, shape, dims, times, 2, "f64", q, boundary))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -1107,8 +1141,8 @@ def test_three_rank_dirichlet_slabs_on_one_gpu(L, O, shape, dims, times):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    exp = O.run_bc(shape, O.reference_input(shape, dims), times, "dirichlet")
-    assert fused
+    exp = O.run_bc(shape, O.reference_input(shape, dims), times, boundary)
+    assert fused == (boundary == "dirichlet")
     if np.abs(exp).max() < 2.0 ** 53:
         assert np.array_equal(got, exp)
     else:
