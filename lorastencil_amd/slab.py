@@ -106,8 +106,8 @@ def slab_layout(shape, global_dims: Sequence[int], world_size: int, rank: int, m
     end_u = start_u + base + (1 if rank < extra else 0)
     begin, end = start_u * multiple, min(end_u * multiple, n0)
     lay = SlabLayout(sid, tuple(int(d) for d in global_dims), world_size, rank, begin, end,
-                     ghost if world_size > 1 else 0, ring and world_size > 1)
-    if world_size > 1 and end - begin < max(lay.radius0, ghost):
+                     ghost if (world_size > 1 or ring) else 0, ring)
+    if (world_size > 1 or ring) and end - begin < max(lay.radius0, ghost):
         raise ValueError("slab thinner than its ghost zone")
     return lay
 
@@ -171,13 +171,16 @@ class SlabDriver:
     def __init__(self, shape, global_dims: Sequence[int], group=None, device=None, params=None, weights=None,
                  stepper_factory: Callable[[SlabLayout], object] | None = None, overlap: bool = True,
                  exchange_every: int | None = None, fused: bool | None = None, boundary_rows: int | None = None,
-                 dtype="f64", boundary: str = "reference"):
+                 dtype="f64", boundary: str = "reference", ring_of_one: bool = False):
         if boundary not in ("reference", "dirichlet", "periodic"):
             raise ValueError("boundary must be reference, dirichlet or periodic")
         self.dirichlet = boundary == "dirichlet"
         self.periodic = boundary == "periodic"
         if self.periodic:
             fused = False  # single sweeps, each preceded by the wrap of the unsplit dimensions
+        # ring_of_one (periodic only): a single rank is treated as a ring of one slab that exchanges its ghost rows
+        # with ITSELF through the process group -- the complete exchange path (P2P batch, overlap, waits) over the real
+        # RCCL backend on a one-GPU box
         self.group = group
         self._host_side_p2p = dist.is_initialized() and dist.get_backend(group) != "nccl"
         self.exchange_mode = os.environ.get("LORA_SLAB_EXCHANGE", "p2p")  # "p2p" (default) or "allgather"
@@ -186,12 +189,13 @@ class SlabDriver:
         self._p2p_worked = False
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self._ring = self.periodic and (self.world_size > 1 or (ring_of_one and dist.is_initialized()))
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         sid = ops.shape_id(shape)
         nd = len(global_dims)
         self.ndim = nd
         # a first, ghost-free layout tells how thick the slabs are; the ghost depth is then fitted to them
-        probe = slab_layout(sid, global_dims, self.world_size, self.rank, ring=self.periodic)
+        probe = slab_layout(sid, global_dims, self.world_size, self.rank, ring=self._ring)
         radius = probe.radius0
         if fused is None:
             fused = True  # refined below by what the stepper supports
@@ -207,10 +211,11 @@ class SlabDriver:
         default_apps = 8 if nd == 1 else 2  # applications of a fused launch (lora_plan_stepk)
         for apps in ([default_apps, 1] if fused else [1]):
             need = radius * apps
-            e = max(1, min(exchange_every, thinnest // need if self.world_size > 1 else exchange_every))
-            if self.world_size > 1 and thinnest < need:
+            split = self.world_size > 1 or self._ring
+            e = max(1, min(exchange_every, thinnest // need if split else exchange_every))
+            if split and thinnest < need:
                 continue
-            layout = slab_layout(sid, global_dims, self.world_size, self.rank, ghost=need * e, ring=self.periodic)
+            layout = slab_layout(sid, global_dims, self.world_size, self.rank, ghost=need * e, ring=self._ring)
             stepper = self._make_stepper(layout)
             if apps > 1:
                 has = hasattr(stepper, "stepk_region") or hasattr(stepper, "step2_region")
@@ -234,7 +239,7 @@ class SlabDriver:
             self.strip += self.strip & 1  # 1D regions start on even points
         self.up = self.rank - 1 if self.rank > 0 else None  # neighbour owning smaller indices
         self.down = self.rank + 1 if self.rank < self.world_size - 1 else None
-        if self.periodic and self.world_size > 1:  # a ring: the first and the last slab are neighbours
+        if self._ring:  # the first and the last slab are neighbours (a ring of one: its own neighbour)
             self.up = (self.rank - 1) % self.world_size
             self.down = (self.rank + 1) % self.world_size
         self.steps_done = 0
@@ -289,6 +294,10 @@ class SlabDriver:
         hi = h0 + lay.ghost_top + lay.own + (h0 if edge_bottom else 0)
         piece = cur[lo:hi].cpu()
         if self.world_size == 1:
+            if self._ring:  # a ring of one: the pad rows of the split dimension = its own opposite interior edge
+                n0 = lay.global_dims[0]
+                piece[:h0] = piece[n0:n0 + h0].clone()
+                piece[h0 + n0:] = piece[h0:2 * h0].clone()
             return piece
         pieces = [None] * self.world_size if self.rank == dst_rank else None
         dist.gather_object(piece, pieces, dst=dst_rank, group=self.group)
@@ -356,7 +365,7 @@ class SlabDriver:
 
     def refresh_ghosts(self) -> None:
         """Blocking refresh of the ghost zones of the current buffer (used after loading device-generated data)."""
-        if self.world_size > 1:
+        if self.up is not None or self.down is not None:
             for w in self._post_exchange(self.buf[self.cur]):
                 w.wait()
             self._p2p_worked = True
@@ -383,7 +392,7 @@ class SlabDriver:
             even = self.steps_done % 2 == 0
             self._set_ring(dst_i, "input" if (fused or not even) else "zero", src_i)
         gt, own = lay.ghost_top, lay.own
-        if self.world_size == 1:
+        if self.up is None and self.down is None:
             sweep(src, dst, 0, own)
         else:
             assert self.valid >= need, "ghost zone exhausted"

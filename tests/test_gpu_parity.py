@@ -1150,9 +1150,9 @@ def test_three_rank_dirichlet_slabs_on_one_gpu(L, O, shape, dims, times, boundar
 
 
 def test_rccl_backend_initialises_and_slab_driver_runs_under_it(L, O):
-    """One rank over the real "nccl" (= RCCL) backend: process-group creation with device_id, barrier, all-reduce and
-    a SlabDriver run inside an initialised group.  (Two RCCL ranks need two GPUs; the exchange itself is covered over
-    gloo above.)"""
+    """One rank over the real "nccl" (= RCCL) backend: process-group creation with device_id, barrier, all-reduce, a
+    SlabDriver run inside an initialised group, and the ghost exchange itself -- a periodic ring of one slab exchanges
+    its boundary strips with ITSELF through RCCL (two RCCL ranks would need two GPUs)."""
     script = r'''
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["LORA_ROOT"])
@@ -1167,6 +1167,21 @@ drv.load_global(a); drv.refresh_ghosts(); drv.run(6)
 torch.cuda.synchronize(); dist.barrier()
 t = torch.tensor([1.5], dtype=torch.float64, device="cuda:0"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
 ok = np.array_equal(drv.gather_global().numpy(), O.run("star2d1r", a, 6)) and float(t.item()) == 1.5
+# the ghost exchange itself over RCCL: a periodic ring of ONE slab sends its boundary strips to itself (P2P batch on
+# row slices, boundary-first overlap, waits -- then the all-gather form), compared with the oracle's torus
+for shape, dims, steps in (("star2d1r", (256, 384), 7), ("star3d1r", (24, 20, 64), 5), ("1d1r", (30000,), 6)):
+    a = O.reference_input(shape, dims)
+    exp = O.run_bc(shape, a, steps, "periodic")
+    for mode in ("p2p", "allgather"):
+        os.environ["LORA_SLAB_EXCHANGE"] = mode
+        drv = slab.SlabDriver(shape, dims, device="cuda:0", boundary="periodic", ring_of_one=True, exchange_every=2)
+        assert drv.up == 0 and drv.down == 0 and drv.layout.ghost > 0 and drv.exchange_mode == mode
+        drv.load_global(a); drv.run(steps)
+        got = drv.gather_global().numpy()
+        same = np.array_equal(got, exp) if np.abs(exp).max() < 2.0 ** 53 else np.abs(got - exp).max() <= 1e-13 * np.abs(exp).max()
+        if not same:
+            print("RING_MISMATCH", shape, mode)
+        ok = ok and same
 dist.destroy_process_group()
 print("RCCL_OK" if ok else "RCCL_MISMATCH")
 '''
