@@ -178,18 +178,22 @@ class SlabDriver:
         self.periodic = boundary == "periodic"
         if self.periodic:
             fused = False  # single sweeps, each preceded by the wrap of the unsplit dimensions
-        # ring_of_one (periodic only): a single rank is treated as a ring of one slab that exchanges its ghost rows
-        # with ITSELF through the process group -- the complete exchange path (P2P batch, overlap, waits) over the real
-        # RCCL backend on a one-GPU box
+        # ring_of_one: a single rank is treated as a ring of one slab that exchanges its ghost rows with ITSELF through
+        # the process group -- the complete exchange path (P2P batch, overlap, waits) over the real RCCL backend on a
+        # one-GPU box.  With the periodic boundary the result is the torus (tested against the oracle); with the other
+        # boundaries it is a TIMING rehearsal of one rank's share of an N-GPU run (tools/slab_overhead.py), not a result.
         self.group = group
         self._host_side_p2p = dist.is_initialized() and dist.get_backend(group) != "nccl"
         self.exchange_mode = os.environ.get("LORA_SLAB_EXCHANGE", "p2p")  # "p2p" (default) or "allgather"
         if self.exchange_mode not in ("p2p", "allgather"):
             raise ValueError("LORA_SLAB_EXCHANGE must be p2p or allgather")
         self._p2p_worked = False
+        self._pending = []       # works of a ghost exchange the next launch has not waited for yet
+        self.defer_wait = os.environ.get("LORA_SLAB_DEFER_WAIT", "1") != "0"
         self.world_size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
-        self._ring = self.periodic and (self.world_size > 1 or (ring_of_one and dist.is_initialized()))
+        self._ring = (self.periodic and self.world_size > 1) or (ring_of_one and self.world_size == 1
+                                                                 and dist.is_initialized())
         self.device = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         sid = ops.shape_id(shape)
         nd = len(global_dims)
@@ -205,13 +209,19 @@ class SlabDriver:
             lambda lay: HipStepper(lay, params=params, weights=weights, dtype=self.dtype, boundary=boundary))
         # thinnest slab of the decomposition bounds the ghost depth (neighbours supply ghost rows from own rows)
         thinnest = min(slab_layout(sid, global_dims, self.world_size, r).own for r in range(self.world_size))
-        if exchange_every is None:
-            exchange_every = 4
+        auto_every = exchange_every is None
         layout = None
         default_apps = 8 if nd == 1 else 2  # applications of a fused launch (lora_plan_stepk)
         for apps in ([default_apps, 1] if fused else [1]):
             need = radius * apps
             split = self.world_size > 1 or self._ring
+            if auto_every:
+                # refresh as rarely as keeps the redundant ghost sweeps (about (E - 1) x need rows per launch) within
+                # ~10 % of a slab: 8 launches for the 2D / 1D configurations, 4 for the thin 3D slabs of an 8-GPU run
+                # (ring of one over RCCL, 2048 x 16384 slab: E = 2 / 4 / 8 / 16 -> 492 / 535 / 553 / 534 GStencils/s)
+                exchange_every = 8
+                while exchange_every > 1 and (exchange_every - 1) * need > 0.1 * thinnest:
+                    exchange_every //= 2
             e = max(1, min(exchange_every, thinnest // need if split else exchange_every))
             if split and thinnest < need:
                 continue
@@ -264,6 +274,7 @@ class SlabDriver:
             part = global_padded[lo:hi]
         if isinstance(part, np.ndarray):
             part = torch.from_numpy(np.ascontiguousarray(part))
+        self._flush()
         self.buf[0].copy_(part.to(self.device))
         self.buf[1].zero_()
         self.steps_done, self.cur, self.valid = 0, 0, lay.ghost
@@ -271,6 +282,7 @@ class SlabDriver:
 
     def load_local(self, local_padded: torch.Tensor) -> None:
         """Same from an already-local array (own rows + ghost rows + pads), e.g. generated on the device."""
+        self._flush()
         self.buf[0].copy_(local_padded)
         self.buf[1].zero_()
         self.steps_done, self.cur, self.valid = 0, 0, self.layout.ghost
@@ -278,6 +290,7 @@ class SlabDriver:
 
     def result(self) -> torch.Tensor:
         """The local padded buffer holding the current time level."""
+        self._flush()
         return self.buf[self.cur]
 
     def gather_global(self, dst_rank: int = 0):
@@ -285,6 +298,7 @@ class SlabDriver:
         edge ranks; left/right halos travel with the rows).  Returns a CPU tensor there, None elsewhere."""
         lay = self.layout
         h0 = lay.halo0
+        self._flush()
         if self.periodic:
             self.stepper.wrap(self.buf[self.cur])  # the result is a consistent periodic array (like lora_plan_run)
         cur = self.result()
@@ -365,6 +379,7 @@ class SlabDriver:
 
     def refresh_ghosts(self) -> None:
         """Blocking refresh of the ghost zones of the current buffer (used after loading device-generated data)."""
+        self._flush()
         if self.up is not None or self.down is not None:
             for w in self._post_exchange(self.buf[self.cur]):
                 w.wait()
@@ -383,14 +398,20 @@ class SlabDriver:
         else:
             sweep = self.stepper.step_region
         if self.periodic:
+            self._flush()  # the wrap writes the x / y halo of every row, ghost rows in flight included
             self.stepper.wrap(src)  # x / y (and, on one rank, the split dimension too): halo = opposite interior edge
-        elif self.dirichlet:
-            self._set_ring(dst_i, "input", src_i)  # fixed boundary: every level carries the caller's halo ring
-        elif self.fused or fused:
-            # fused launches need the level-0 ring in both buffers; a single sweep from an even level writes the
-            # odd level, whose ring is 0; from an odd level it writes an even one (ring = input)
-            even = self.steps_done % 2 == 0
-            self._set_ring(dst_i, "input" if (fused or not even) else "zero", src_i)
+        else:
+            ring = None
+            if self.dirichlet:
+                ring = "input"  # fixed boundary: every level carries the caller's halo ring
+            elif self.fused or fused:
+                # fused launches need the level-0 ring in both buffers; a single sweep from an even level writes the
+                # odd level, whose ring is 0; from an odd level it writes an even one (ring = input)
+                even = self.steps_done % 2 == 0
+                ring = "input" if (fused or not even) else "zero"
+            if ring is not None and self.ring[dst_i] != ring:
+                self._flush()  # the ring copy reads the source's halo columns, ghost rows included
+                self._set_ring(dst_i, ring, src_i)
         gt, own = lay.ghost_top, lay.own
         if self.up is None and self.down is None:
             sweep(src, dst, 0, own)
@@ -399,6 +420,7 @@ class SlabDriver:
             left = self.valid - need  # ghost rows still valid after this launch
             exchange = left < self.need  # not enough for another launch of this driver's kind: refresh now
             if exchange:
+                self._flush()  # (only when every launch exchanges)
                 s = self.strip
                 if self.overlap and own > 2 * s:
                     if self.up is not None:
@@ -410,17 +432,36 @@ class SlabDriver:
                 else:
                     sweep(src, dst, gt, gt + own)
                     works = self._post_exchange(dst)
-                for w in works:
-                    w.wait()
-                self._p2p_worked = True
+                # The ghost rows in flight are first read by the NEXT launch, and only by the part of it within
+                # `need` rows of the slab's ends: leave the messages pending -- the next launch sweeps its deep interior
+                # before it waits for them, which doubles the compute the transfer can hide behind.
+                self._pending = list(works)
+                if not self.defer_wait:
+                    self._flush()
                 self.valid = lay.ghost
             else:
                 lo = gt - (left if self.up is not None else 0)
                 hi = gt + own + (left if self.down is not None else 0)
-                sweep(src, dst, lo, hi)
+                a, b = gt + need, gt + own - need  # output rows whose inputs are own rows only
+                if self._pending and b - a >= 2 * need:
+                    sweep(src, dst, a, b)
+                    self._flush()
+                    sweep(src, dst, lo, a)
+                    sweep(src, dst, b, hi)
+                else:
+                    self._flush()
+                    sweep(src, dst, lo, hi)
                 self.valid = left
         self.cur = dst_i
         self.steps_done += apps
+
+    def _flush(self) -> None:
+        """Wait for a ghost exchange left in flight by the previous launch."""
+        if self._pending:
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+            self._p2p_worked = True
 
     def step(self) -> None:
         """One kernel application."""
