@@ -12,9 +12,19 @@ Inputs are synthetic small integers (0..99, the range of the reference's rand()%
 and resident in HBM before the timed region.  For N > 1 the SAME 16384^2 grid is cut into N row slabs ("strong"
 scaling, as BASELINE.json quotes the metric) with one RCCL halo exchange per step overlapped with the interior.
 
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks (a
+torch.distributed.run child, before this process touches the GPU) and relays rank 0's line.
+
 The single JSON line also carries
-  roofline      algorithmic bytes (2 x 8 B per interior point per sweep) / average launch duration
-                measured with HIP events on the launch stream, against the 8 TB/s HBM3E peak;
+  roofline      for the dominant kernel: COMPULSORY bytes per launch (one read + one write of every interior point,
+                2 x sizeof(T) x points, however many applications the launch fuses) / its average launch duration
+                (HIP events on the launch stream around the fused launches of the timed region,
+                lora_plan_run_profiled), against the 8 TB/s HBM3E peak: `frac` <= 1 by construction.
+                `frac_one_sweep_equiv` is SURVEY 8d's figure (16 B per point per APPLICATION: > 1 means the fused
+                launch beats what any one-sweep-per-launch kernel could reach); `copy_bw_frac` relates `achieved` to
+                a torch copy_ of the same grid timed in this run; `traffic` = measured HBM bytes per launch (rocprofv3
+                PMC passes, profiles/pmc_traffic.json, keyed by the kernel's full signature: null when that exact
+                instantiation has not been measured);
   cpu_baseline  the CPU oracle (a port of the reference's test_cpu loop) timed on this box's host cores on a
                 bounded sample of the same workload (rank 0, N = 1 only).
 """
@@ -45,6 +55,9 @@ def parse_args():
     ap.add_argument("--option", action="append", default=[], help="plan option key=value (e.g. rows_per_thread=4)")
     ap.add_argument("--variant", choices=["auto", "direct", "mfma"], default="auto")
     ap.add_argument("--dtype", choices=["f64", "bf16"], default="f64", help="bf16: 3D shapes only (BASELINE config 5)")
+    ap.add_argument("--plumbing-only", action="store_true",
+                    help="start the ranks, rendezvous, reduce a clock and print a line with value null: checks the "
+                         "launch path on a box without a GPU (no kernel runs, nothing is measured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
@@ -124,8 +137,46 @@ def cpu_baseline(shape, dims, budget_s):
     }
 
 
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` (N > 1) outside a torch.distributed launch: start the N ranks ourselves, as a CHILD
+    process, before this one has made any GPU call (a process that has initialised the GPU must not exec another
+    program on this pool), and pass rank 0's JSON line and the children's exit status through."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if (proc.returncode != 0 or line is not None) else 1
+
+
+def planned_launches(ndim, times, spl, fused_ok=True):
+    """(fused launches, single-sweep launches) of one run: the rule of run_launches() in csrc/capi.cpp -- an even
+    number of K-application launches while at least 2 K steps remain, then single sweeps."""
+    if spl < 2 or not fused_ok or times < 2 * spl:
+        return 0, times
+    pairs = (times // spl) & ~1
+    return pairs, times - spl * pairs
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     import torch
     import torch.distributed as dist
 
@@ -146,13 +197,25 @@ def main():
                 time.sleep(2)
             time.sleep(5)  # let the linker finish writing
 
+    args.gpus = world  # inside a launch the launcher's world size is authoritative
+    if args.plumbing_only:
+        # the N-rank launch path without the engine: rendezvous over gloo, one MAX-reduction, one line from rank 0
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        t = torch.tensor([time.perf_counter()], dtype=torch.float64)
+        if world > 1:
+            dist.init_process_group("gloo")
+            dist.barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": "GStencils/s", "value": None, "unit": "GStencils/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "plumbing_only": True}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     import lorastencil_amd as L
     from lorastencil_amd import slab
 
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (the engine has no CPU fallback)"
     # LORA_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a 1-GPU box)
     backend = os.environ.get("LORA_DIST_BACKEND", "nccl")
@@ -202,6 +265,7 @@ def main():
         b0, b1 = src0.clone(), torch.zeros(ps, dtype=tdtype, device=dev)
         run = lambda n: plan.run(b0, b1, n)  # noqa: E731
         kernel = plan.kernel_name
+        signature = plan.kernel_signature
         local_points = 1
         for d in dims:
             local_points *= d
@@ -210,15 +274,15 @@ def main():
             b0.copy_(src0)
             b1.zero_()
     else:
-        drv = slab.SlabDriver(shape, dims, device=dev, weights=weights, dtype=args.dtype)
+        # options and variant go in BEFORE the driver fixes its ghost depth (they decide applications per launch)
+        drv = slab.SlabDriver(shape, dims, device=dev, weights=weights, dtype=args.dtype, options=opts,
+                              variant=None if variant == L.VARIANT_AUTO else variant)
         plan = drv.stepper.plan
-        if variant != L.VARIANT_AUTO:
-            plan.set_variant(variant)
-        for k, v in opts.items():
-            plan.set_option(k, int(v))
+        assert drv.stepper.apps_per_launch == (drv.apps if drv.fused else drv.stepper.apps_per_launch)
         src0 = torch.randint(0, 100, drv.local_padded_shape, generator=gen, device=dev).to(tdtype)
         run = lambda n: drv.run(n)  # noqa: E731
         kernel = plan.kernel_name
+        signature = plan.kernel_signature
         local_points = drv.layout.own
         for d in drv.layout.local_dims[1:]:
             local_points *= d
@@ -227,14 +291,33 @@ def main():
             drv.load_local(src0)
             drv.refresh_ghosts()  # neighbours' own rows of time level 0 into the ghost zones
 
+    # achievable-bandwidth reference of THIS box, in this run: a device copy of the same grid (read + write once)
+    copy_gbs = None
+    if world == 1:
+        dst_c = torch.empty_like(src0)
+        dst_c.copy_(src0)
+        torch.cuda.synchronize()
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            dst_c.copy_(src0)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2.0 * src0.numel() * esize * 5 / (c0.elapsed_time(c1) / 1e3) / 1e9
+        del dst_c
+
     reset()
     run(W)
     reset()  # keep the value range of the timed steps independent of the warm-up length
     barrier()
+    prof = None
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()
-    run(K)
+    if world == 1:
+        prof = plan.run_profiled(b0, b1, K)  # = plan.run + events around its fused / single-sweep launches; blocks
+    else:
+        run(K)
     ev1.record()
     barrier()
     t1 = time.perf_counter()
@@ -249,20 +332,31 @@ def main():
     for d in dims:
         points *= d
     value = points * K / elapsed / 1e9
-    # one launch applies `spl` sweeps (temporal fusion); algorithmic bytes stay 2 x 8 B per point per APPLICATION
+    # The dominant kernel and its average launch duration over the timed region.  One launch applies `spl` sweeps
+    # (temporal fusion) but moves the grid through HBM once: compulsory bytes per launch = 2 x sizeof(T) x points.
     if world == 1:
         spl = plan.get_option("steps_per_launch")
+        if prof.fused_launches > 0:
+            launches, apps, launch_s = prof.fused_launches, prof.apps_per_fused_launch, prof.fused_ms / 1e3 / prof.fused_launches
+        else:
+            launches, apps, launch_s = max(prof.single_launches, 1), 1, prof.single_ms / 1e3 / max(prof.single_launches, 1)
+            single = L.Plan(shape, dims, dtype=args.dtype).set_weights(weights).set_option("steps_per_launch", 1)
+            kernel, signature = single.kernel_name, single.kernel_signature
     else:
         spl = drv.apps if drv.fused else 1
-    launches = max(1, K // spl) if spl > 1 else K
-    launch_s = ev_ms / 1e3 / launches  # average launch duration on the launch stream (HIP events)
-    bytes_per_launch = local_points * 2.0 * esize * (K / launches)
+        nf, ns = planned_launches(len(dims), K, spl, drv.fused)
+        # slab launches are issued from Python in pieces (boundary strips, interior): count applications, not pieces
+        launches, apps = (nf, spl) if nf else (ns, 1)
+        launch_s = ev_ms / 1e3 * (nf * spl / K if nf else 1.0) / max(launches, 1)
+    bytes_per_launch = local_points * 2.0 * esize          # compulsory: one read + one write of the grid
     achieved = bytes_per_launch / launch_s / 1e9
+    one_sweep_equiv = achieved * apps                       # 2 x sizeof(T) per point per APPLICATION
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    tkey = f"{shape}:{'x'.join(map(str, dims))}:{world}:{signature}"
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(f"{shape}:{'x'.join(map(str, dims))}:{world}:{kernel}")
+            traffic = json.load(open(tpath)).get(tkey)  # a miss stays null: never a number measured on another kernel
         except Exception:
             traffic = None
 
@@ -293,16 +387,22 @@ def main():
             "value_reference_convention": round(value * L.ops.gstencil_factor(shape), 3),
             "roofline": {
                 "bound": "hbm",
+                "kernel": signature,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": traffic,
-                # the same launch duration applied to the MEASURED bytes: the real HBM rate behind `achieved`
+                # the same launch duration applied to the MEASURED bytes
                 "traffic_gbs": round(traffic / launch_s / 1e9, 1) if traffic else None,
+                "traffic_key": tkey,
                 "launch_us": round(launch_s * 1e6, 2),
+                "launches": launches,
                 "bytes_per_launch": round(bytes_per_launch),
-                "applications_per_launch": spl,
+                "applications_per_launch": apps,
+                "frac_one_sweep_equiv": round(one_sweep_equiv / HBM_PEAK_GBS, 4),
+                "copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
+                "copy_bw_frac": round(achieved / copy_gbs, 4) if copy_gbs else None,
             },
         }
         if world == 1 and not args.no_cpu_baseline and not bf16:

@@ -177,14 +177,21 @@ int lora_set_default_boundary(int boundary);
  *                     order; the oracle restates both orders, see lora_separable_3x3x3)
  *   cols_per_lane, lds_dma, fused_pipeline                              bf16 kernel variants
  *   graph             -1 auto / 0 / 1 : hipGraph replay of lora_plan_run
- *   ablate            DIAGNOSTIC (2D fused and bf16 3D kernels): 1 = skip stores, 2 = skip loads -- timing experiments whose
- *                     RESULTS ARE WRONG by construction; never set outside profiling
+ *   stream            2D fused launches: 1 = row-streaming kernel (wave-autonomous column strips, kernels_2d_stream.hip),
+ *                     0 = tile kernel; stream_rows (output rows per chunk, 0 = auto), stream_depth (2..6 input rows in
+ *                     flight per wave), stream_sync (one barrier per 7 rows keeps a workgroup's strips in step)
+ * ("ablate", the load/store-removing timing experiment of round 1, exists only in -DLORA_DIAGNOSTICS builds of the
+ * library; the shipped one answers LORA_EINVAL.)
  * lora_plan_get_option also reads the resolved "tapset", "variant", "fused_eval", "boundary". */
 int lora_plan_set_option(lora_plan *plan, const char *key, int value);
 int lora_plan_get_option(const lora_plan *plan, const char *key, int *value);
 size_t lora_plan_padded_bytes(const lora_plan *plan);
 /* Name of the kernel a sweep of this plan launches (for matching rocprof rows). */
 const char *lora_plan_kernel_name(const lora_plan *plan);
+/* The same plus every resolved option that selects the kernel instantiation or its launch geometry, e.g.
+ * "stencil2d_stream2_kernel[eval=3,depth=4,sync=1,rows=589]": the key measured per-launch HBM traffic is filed under
+ * (profiles/pmc_traffic.json), so that a changed option can never be paired with a stale measurement. */
+const char *lora_plan_kernel_signature(const lora_plan *plan);
 
 /* One kernel application: interior of d_out <- stencil(d_in).  Halo cells of d_out are not
  * touched (2d/gpu.cu:266-271). */
@@ -216,6 +223,19 @@ int lora_plan_halo(lora_plan *plan, void *d_dst, const void *d_src, int mode, vo
  * buffers starting from d_buf0; the result is in buffer [times % 2].  The caller must have put
  * the padded input in d_buf0 and zeros in d_buf1 to get the reference semantics. */
 int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream);
+/* lora_plan_run with HIP events recorded on `stream` around its two kinds of launches -- the fused multi-application
+ * launches and the single-sweep tail -- so that a caller can quote the average duration of the dominant kernel over
+ * the very region it timed (bench.py's roofline).  Launches directly (no hipGraph) and BLOCKS until the run has
+ * finished.  Halo bookkeeping kernels (O(surface)) are inside the fused segment. */
+typedef struct lora_run_profile {
+    int fused_launches;        /* launches of the K-application kernel            */
+    int apps_per_fused_launch; /* K (1 if the plan does not fuse)                 */
+    int single_launches;       /* single-sweep launches (the whole run if K = 1)  */
+    float fused_ms;            /* event time of the fused segment                 */
+    float single_ms;           /* event time of the single-sweep segment          */
+} lora_run_profile;
+int lora_plan_run_profiled(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream,
+                           lora_run_profile *profile);
 void lora_plan_destroy(lora_plan *plan);
 
 /* ========================================================================================

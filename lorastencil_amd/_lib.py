@@ -11,8 +11,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# LORASTENCIL_LIB: another build of the SAME engine (A/B timing of kernel changes on one GPU box); never a fallback
-LIB_PATH = os.environ.get("LORASTENCIL_LIB") or os.path.join(_HERE, "lib", "liblorastencil_hip.so")
+# The one engine library, in-tree.  (Development tools that A/B two builds assign LIB_PATH before the first lib() call;
+# no environment variable can swap the engine under the product.)
+LIB_PATH = os.path.join(_HERE, "lib", "liblorastencil_hip.so")
 
 LORA_OK = 0
 LORA_EINVAL = -1
@@ -46,6 +47,16 @@ class RunInfo(ctypes.Structure):
         ("hbm_gbs", ctypes.c_double),
         ("variant", ctypes.c_int),
         ("steps_per_launch", ctypes.c_int),
+    ]
+
+
+class RunProfile(ctypes.Structure):
+    _fields_ = [
+        ("fused_launches", ctypes.c_int),
+        ("apps_per_fused_launch", ctypes.c_int),
+        ("single_launches", ctypes.c_int),
+        ("fused_ms", ctypes.c_float),
+        ("single_ms", ctypes.c_float),
     ]
 
 
@@ -86,6 +97,8 @@ SIGNATURES = {
     "lora_set_default_boundary": (ctypes.c_int, [ctypes.c_int]),
     "lora_plan_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
     "lora_plan_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _ip]),
+    "lora_plan_kernel_signature": (ctypes.c_char_p, [_vp]),
+    "lora_plan_run_profiled": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.POINTER(RunProfile)]),
     "lora_plan_padded_bytes": (ctypes.c_size_t, [_vp]),
     "lora_plan_kernel_name": (ctypes.c_char_p, [_vp]),
     "lora_plan_step": (ctypes.c_int, [_vp, _vp, _vp, _vp]),

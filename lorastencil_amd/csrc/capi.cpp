@@ -218,7 +218,8 @@ void plan_refresh(Plan &p) {
         p.kernel_name = p.generic ? kernel_name_generic(p)
                         : (p.variant == LORA_VARIANT_MFMA)
                             ? kernel_name_2d_mfma(p)
-                            : (p.steps_per_launch == 2 ? kernel_name_2d_fused2(p) : kernel_name_2d_direct(p));
+                            : (p.steps_per_launch == 2 ? (p.stream2 ? kernel_name_2d_stream2(p) : kernel_name_2d_fused2(p))
+                                                       : kernel_name_2d_direct(p));
     } else if (p.ndim == 3) {
         bool star = true;
         for (int k = 0; k < 27; ++k) {
@@ -346,6 +347,10 @@ int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, con
         return LORA_EUNSUPPORTED;
     }
     if ((double) lora_padded_count(shape, dims) >= 2147483647.0 * 64) return LORA_EUNSUPPORTED;
+    if (nd == 1 && dims[0] > 2147483647 - 4096) {
+        g_last_error = "1D extent too large (kernels index the padded array with 32-bit integers)";
+        return LORA_EUNSUPPORTED;
+    }
     lora_plan *pl = new (std::nothrow) lora_plan();
     if (!pl) return LORA_ENOMEM;
     Plan &p = pl->p;
@@ -449,6 +454,16 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         p.nt_store = value ? 1 : 0;
     } else if (!std::strcmp(key, "persistent")) {
         p.persistent = value ? 1 : 0;
+    } else if (!std::strcmp(key, "stream")) {
+        p.stream2 = value ? 1 : 0;
+    } else if (!std::strcmp(key, "stream_rows")) {
+        if (value < 0 || value > (1 << 20)) return LORA_EINVAL;
+        p.stream_rows = value;
+    } else if (!std::strcmp(key, "stream_depth")) {
+        if (value < 2 || value > 6) return LORA_EINVAL;
+        p.stream_depth = value;
+    } else if (!std::strcmp(key, "stream_sync")) {
+        p.stream_sync = value ? 1 : 0;
     } else if (!std::strcmp(key, "graph")) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.use_graph = value;
@@ -459,7 +474,12 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.separable = value;
     } else if (!std::strcmp(key, "ablate")) {
+#ifdef LORA_DIAGNOSTICS
         p.ablate = value & 3;
+#else
+        g_last_error = "option \"ablate\" exists only in -DLORA_DIAGNOSTICS builds";
+        return LORA_EINVAL;  // wrong-results timing experiments are not part of the shipped library
+#endif
     } else if (!std::strcmp(key, "lds_dma")) {
         p.lds_dma = value ? 1 : 0;
     } else if (!std::strcmp(key, "cols_per_lane")) {
@@ -502,6 +522,14 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.persistent;
     else if (!std::strcmp(key, "graph"))
         *value = p.use_graph;
+    else if (!std::strcmp(key, "stream"))
+        *value = p.stream2;
+    else if (!std::strcmp(key, "stream_rows"))
+        *value = p.stream_rows;
+    else if (!std::strcmp(key, "stream_depth"))
+        *value = p.stream_depth;
+    else if (!std::strcmp(key, "stream_sync"))
+        *value = p.stream_sync;
     else if (!std::strcmp(key, "boundary"))
         *value = p.boundary;
     else if (!std::strcmp(key, "fused_eval"))
@@ -538,6 +566,36 @@ size_t lora_plan_padded_bytes(const lora_plan *plan) {
 
 const char *lora_plan_kernel_name(const lora_plan *plan) { return plan ? plan->p.kernel_name.c_str() : ""; }
 
+const char *lora_plan_kernel_signature(const lora_plan *plan) {
+    if (!plan) return "";
+    const Plan &p = plan->p;
+    static thread_local std::string sig;
+    char buf[256];
+    const std::string &k = p.kernel_name;
+    buf[0] = 0;
+    if (k == "stencil2d_stream2_kernel")
+        std::snprintf(buf, sizeof buf, "eval=%d,depth=%d,sync=%d,rows=%d,bc=%d", p.fused_eval,
+                      p.boundary == LORA_BC_DIRICHLET ? 4 : p.stream_depth, p.stream_sync,
+                      lora::stream2_rows_per_chunk(p, p.dims[0], (p.dims[1] + 115) / 116), p.boundary);
+    else if (k == "stencil2d_fused2_kernel")
+        std::snprintf(buf, sizeof buf, "eval=%d,rows=%d,persist=%d,panel=%d,bc=%d", p.fused_eval, p.fused_rows,
+                      p.persistent, p.panel_width, p.boundary);
+    else if (k == "stencil2d_direct_kernel")
+        std::snprintf(buf, sizeof buf, "taps=%d,rpt=%d,nt=%d,panel=%d", p.tapset, p.rows_per_thread, p.nt_store,
+                      p.panel_width);
+    else if (k == "stencil2d_mfma_kernel")
+        std::snprintf(buf, sizeof buf, "rank=%d,panel=%d", p.lowrank.rank, p.panel_width);
+    else if (p.ndim == 3 && p.dtype == LORA_BF16)
+        std::snprintf(buf, sizeof buf, "taps=%d,zc=%d,fzc=%d,cpl=%d,dma=%d,pipe=%d,bc=%d", p.tapset, p.z_chunk,
+                      p.fused_z_chunk, p.cols_per_lane, p.lds_dma, p.fused_pipeline, p.boundary);
+    else if (p.ndim == 3)
+        std::snprintf(buf, sizeof buf, "taps=%d,zc=%d,fzc=%d,bc=%d", p.tapset, p.z_chunk, p.fused_z_chunk, p.boundary);
+    else if (p.ndim == 1)
+        std::snprintf(buf, sizeof buf, "k=%d", p.steps_per_launch);
+    sig = k + "[" + buf + "]";
+    return sig.c_str();
+}
+
 int lora_plan_region_granularity(const lora_plan *plan) { return plan ? lora::region_granularity(plan->p) : 0; }
 
 int lora_plan_step_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream) {
@@ -558,8 +616,9 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
     if (!ok2 && !ok3) return LORA_EUNSUPPORTED;
     if (int rc = lora::check_buffers(d_in, d_out)) return rc;
     if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
-    const hipError_t e = ok2 ? lora::launch_2d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),
-                                                      begin, end, static_cast<hipStream_t>(stream))
+    const hipError_t e = ok2 ? (p.stream2 ? lora::launch_2d_stream2 : lora::launch_2d_fused2)(
+                                   p, static_cast<const double *>(d_in), static_cast<double *>(d_out), begin, end,
+                                   static_cast<hipStream_t>(stream))
                          : p.dtype == LORA_BF16
                              ? lora::launch_3d_bf16_fused2(p, d_in, d_out, begin, end, static_cast<hipStream_t>(stream))
                              : lora::launch_3d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),
@@ -617,11 +676,24 @@ int lora_plan_stepk(lora_plan *plan, const void *d_in, void *d_out, void *stream
 }
 
 // The launches of one run, in order, on `stream` (also what gets captured into a hipGraph).
-static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream) {
+struct RunMarks {  // lora_plan_run_profiled: events around the fused and the single-sweep segment
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int fused_launches = 0, single_launches = 0;
+};
+
+static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream, RunMarks *marks = nullptr) {
     Plan &p = plan->p;
     void *buf[2] = {d_buf0, d_buf1};
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (times == 0) return LORA_OK;
+    auto mark = [&](int k) {
+        if (marks) (void) hipEventRecord(marks->ev[k], s);
+    };
+    mark(0);
+    if (times == 0) {
+        mark(1);
+        mark(2);
+        return LORA_OK;
+    }
     auto halo = [&](void *dst, const void *src, int mode, const char *what) -> int {
         const hipError_t e = lora::launch_halo(p, dst, src, mode, s);
         if (e != hipSuccess) {
@@ -638,11 +710,15 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
         // torus: refresh the source's halo from the opposite interior edges before every sweep, and once more at the
         // end so that the result is a consistent periodic array (single sweeps: a fused launch would need the wrap
         // of its intermediate level)
+        mark(1);
         for (int i = 0; i < times; ++i) {
             if (int rc = halo(buf[i % 2], nullptr, lora::HALO_WRAP, "periodic halo")) return rc;
             if (int rc = lora_plan_step(plan, buf[i % 2], buf[(i + 1) % 2], stream)) return rc;
         }
-        return halo(buf[times % 2], nullptr, lora::HALO_WRAP, "periodic halo");
+        if (marks) marks->single_launches = times;
+        const int rc = halo(buf[times % 2], nullptr, lora::HALO_WRAP, "periodic halo");
+        mark(2);
+        return rc;
     }
 
     const bool dirichlet = p.boundary == LORA_BC_DIRICHLET;
@@ -651,7 +727,6 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
         if (int rc = halo(buf[1], buf[0], lora::HALO_COPY, "halo copy")) return rc;
     }
     int done = 0;
-    // 3D fused launches implement the reference boundary only (level-1 halo = 0)
     const int K = p.steps_per_launch;  // applications per fused launch: 2 (2D, 3D) or 2 / 4 / 8 (1D)
     const bool can_fuse = K >= 2 && !p.generic &&
                           ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) || p.ndim == 3 || p.ndim == 1);
@@ -672,11 +747,15 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
         if (!dirichlet)
             if (int rc = halo(buf[1], nullptr, lora::HALO_ZERO, "halo reset")) return rc;
         done = K * pairs;
+        if (marks) marks->fused_launches = pairs;
     }
+    mark(1);
     for (int i = done; i < times; ++i) {  // 2d/gpu.cu:544-546
         const int rc = lora_plan_step(plan, buf[i % 2], buf[(i + 1) % 2], stream);
         if (rc != LORA_OK) return rc;
     }
+    if (marks) marks->single_launches = times - done;
+    mark(2);
     return LORA_OK;
 }
 
@@ -741,6 +820,29 @@ int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *
         lora::set_last_error("hipGraphLaunch", e);
         return LORA_EHIP;
     }
+    return LORA_OK;
+}
+
+int lora_plan_run_profiled(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream,
+                           lora_run_profile *profile) {
+    if (!plan || times < 0 || !profile) return LORA_EINVAL;
+    RunMarks marks;
+    struct Guard {
+        RunMarks &m;
+        ~Guard() {
+            for (hipEvent_t e : m.ev)
+                if (e) (void) hipEventDestroy(e);
+        }
+    } guard{marks};
+    for (hipEvent_t &e : marks.ev) LORA_HIP_TRY(hipEventCreate(&e));
+    const int rc = run_launches(plan, d_buf0, d_buf1, times, stream, &marks);
+    if (rc != LORA_OK) return rc;
+    LORA_HIP_TRY(hipEventSynchronize(marks.ev[2]));
+    profile->fused_launches = marks.fused_launches;
+    profile->apps_per_fused_launch = marks.fused_launches ? plan->p.steps_per_launch : 1;
+    profile->single_launches = marks.single_launches;
+    LORA_HIP_TRY(hipEventElapsedTime(&profile->fused_ms, marks.ev[0], marks.ev[1]));
+    LORA_HIP_TRY(hipEventElapsedTime(&profile->single_ms, marks.ev[1], marks.ev[2]));
     return LORA_OK;
 }
 

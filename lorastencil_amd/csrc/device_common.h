@@ -7,6 +7,14 @@
 
 namespace lora {
 
+// Timing experiments that remove loads / stores from a kernel (plan option "ablate", results wrong by construction)
+// exist only in builds made with -DLORA_DIAGNOSTICS; in the shipped library the expression folds to 0.
+#ifdef LORA_DIAGNOSTICS
+#define LORA_ABLATE(a) ((a).ablate)
+#else
+#define LORA_ABLATE(a) 0
+#endif
+
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 

@@ -56,7 +56,7 @@ struct BandsDev {
 };
 
 template <int RANK>
-__global__ __launch_bounds__(256, 3) void stencil2d_mfma_kernel(const ArgsMfma a, const BandsDev *__restrict__ bands) {
+__global__ __launch_bounds__(256, 3) void stencil2d_mfma_kernel(const ArgsMfma a, const BandsDev bands) {
     __shared__ __attribute__((aligned(16))) double tile[kLH * kLW];
     __shared__ double sb[2 * 3 * 40];
 
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 3) void stencil2d_mfma_kernel(const ArgsMfma a
                 stage[it] = *reinterpret_cast<const d2 *>(a.in + (size_t) gr * a.ld + gc);
             }
         }
-        if (tid < 240) sb[tid] = (tid < 120) ? bands->ub[0][tid] : bands->vb[0][tid - 120];
+        if (tid < 240) sb[tid] = (tid < 120) ? bands.ub[0][tid] : bands.vb[0][tid - 120];
 #pragma unroll
         for (int it = 0; it < kNIT; ++it) {
             const int k = tid + it * 256;
@@ -133,10 +133,10 @@ __global__ __launch_bounds__(256, 3) void stencil2d_mfma_kernel(const ArgsMfma a
 
     // ---- residual taps on the vector pipe (star2d1r: the reference's 8-point correction, 2d/gpu.cu:249-264) ----
     // D layout: register r of lane (j + 16 g) is output (row g + 4r, column 16 q + j) of the wave's sub-tile.
-    const int nres = bands->nresid;
+    const int nres = bands.nresid;
     for (int k = 0; k < nres; ++k) {
-        const int dy = bands->rdy[k], dx = bands->rdx[k];
-        const double w = bands->rw[k];
+        const int dy = bands.rdy[k], dx = bands.rdx[k];
+        const double w = bands.rw[k];
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
@@ -156,17 +156,9 @@ __global__ __launch_bounds__(256, 3) void stencil2d_mfma_kernel(const ArgsMfma a
     }
 }
 
-// device copy of the band tables, one per (device, plan weights); tiny, so it is simply re-uploaded when the
-// plan's factors change
-struct BandCache {
-    BandsDev host{};
-    BandsDev *dev = nullptr;
-    int device = -1;
-    bool valid = false;
-};
-thread_local BandCache g_cache;
-
-hipError_t upload_bands(const LowRank2D &lr, const BandsDev **out) {
+// The band tables travel as a kernel argument (2.2 KB of the 4 KB kernarg segment): no device allocation, no upload,
+// nothing to synchronise when a plan's factors change, and the launch can be captured into a hipGraph.
+BandsDev make_bands(const LowRank2D &lr) {
     BandsDev h{};
     for (int t = 0; t < lr.rank; ++t)
         for (int e = 0; e < 7; ++e) {
@@ -179,35 +171,14 @@ hipError_t upload_bands(const LowRank2D &lr, const BandsDev **out) {
         h.rdx[k] = lr.rdx[k];
         h.rw[k] = lr.rw[k];
     }
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    BandCache &c = g_cache;
-    if (!(c.valid && c.device == dev && std::memcmp(&c.host, &h, sizeof(h)) == 0)) {
-        if (!c.dev || c.device != dev) {
-            e = hipMalloc(reinterpret_cast<void **>(&c.dev), sizeof(BandsDev));
-            if (e != hipSuccess) return e;
-        }
-        // synchronous copy: the table may be replaced while older launches are still queued on other streams
-        e = hipDeviceSynchronize();
-        if (e != hipSuccess) return e;
-        e = hipMemcpy(c.dev, &h, sizeof(h), hipMemcpyHostToDevice);
-        if (e != hipSuccess) return e;
-        c.host = h;
-        c.device = dev;
-        c.valid = true;
-    }
-    *out = c.dev;
-    return hipSuccess;
+    return h;
 }
 
 }  // namespace
 
 hipError_t launch_2d_mfma(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
     if (!p.lowrank_valid) return hipErrorNotSupported;
-    const BandsDev *bands = nullptr;
-    hipError_t e = upload_bands(p.lowrank, &bands);
-    if (e != hipSuccess) return e;
+    const BandsDev bands = make_bands(p.lowrank);
     ArgsMfma a;
     a.in = in;
     a.out = out;

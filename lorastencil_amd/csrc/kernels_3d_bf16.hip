@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 4 : 3)) void stencil3d_bf16_kernel
     auto consume = [&](int p, auto phase_tag) {
         constexpr int PHASE = decltype(phase_tag)::value;
         const bool more = p + 1 < nplanes;
-        if (more && !(a.ablate & 2)) load_plane(p + 1);
+        if (more && !(LORA_ABLATE(a) & 2)) load_plane(p + 1);
         const u16 *strip = reinterpret_cast<const u16 *>(&tile[p & 1][0]) + strip_off;
         f2 u[RY][CPL / 2];  // y-pass partial sums of this plane (separable form only)
 #pragma unroll
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 4 : 3)) void stencil3d_bf16_kernel
         {
             constexpr int s = (PHASE - 2 + 3) % 3;
             const int o = p - 2;
-            if (o >= 0 && o < zc && col_ok && !(a.ablate & 1)) {
+            if (o >= 0 && o < zc && col_ok && !(LORA_ABLATE(a) & 1)) {
                 u16 *dst = out_col + (long) (k0 + o + 1) * a.plane;
 #pragma unroll
                 for (int r = 0; r < RY; ++r) {
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256, 3) void stencil3d_bf16_fused2_kernel(const Arg
     // output plane o of the chunk, complete in slot `s` of acc2
     auto store_plane = [&](int o, auto slot_tag) {
         constexpr int s = decltype(slot_tag)::value;
-        if (o >= 0 && o < zc && col_out && !(a.ablate & 1)) {
+        if (o >= 0 && o < zc && col_out && !(LORA_ABLATE(a) & 1)) {
             u16 *dst = out_col + (long) (k0 + o + 1) * a.plane;
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256, 3) void stencil3d_bf16_fused2_kernel(const Arg
     auto consume = [&](int p, auto phase_tag) {
         constexpr int PH = decltype(phase_tag)::value;  // p mod 3
         const bool more = p + 1 < nin;
-        if (more && !(a.ablate & 2)) load_plane(p + 1);
+        if (more && !(LORA_ABLATE(a) & 2)) load_plane(p + 1);
         if constexpr (PIPE) {
             if (p < nin) sweep_tile(A[p & 1], acc1, std::integral_constant<int, PH>{});
             // level-1 plane p-2 (phase (p-2) mod 3), published during the previous iteration

@@ -315,6 +315,11 @@ class Plan:
         return _lib.lib().lora_plan_kernel_name(self._h).decode()
 
     @property
+    def kernel_signature(self) -> str:
+        """Kernel name + every resolved option that selects the instantiation / launch geometry."""
+        return _lib.lib().lora_plan_kernel_signature(self._h).decode()
+
+    @property
     def weights(self) -> np.ndarray:
         w = np.zeros(ntaps(self.shape))
         check(_lib.lib().lora_plan_get_weights(self._h, _p(w), w.size), "lora_plan_get_weights")
@@ -377,6 +382,14 @@ class Plan:
     def stepk_region(self, d_in, d_out, begin: int, end: int, stream=None):
         check(_lib.lib().lora_plan_stepk_region(self._h, _ptr(d_in), _ptr(d_out), int(begin), int(end),
                                                 _stream(stream)), "lora_plan_stepk_region")
+
+    def run_profiled(self, d_buf0, d_buf1, times: int, stream=None):
+        """run() with HIP events around the fused and the single-sweep launches; blocks until the run is done.
+        Returns a ``_lib.RunProfile``."""
+        prof = _lib.RunProfile()
+        check(_lib.lib().lora_plan_run_profiled(self._h, _ptr(d_buf0), _ptr(d_buf1), int(times), _stream(stream),
+                                                ctypes.byref(prof)), "lora_plan_run_profiled")
+        return prof
 
     def run(self, d_buf0, d_buf1, times: int, stream=None):
         """`times` sweeps ping-ponging from d_buf0; the result is in buffer [times % 2]."""

@@ -34,6 +34,7 @@ inject one to exercise the decomposition, ghost-zone bookkeeping and exchange lo
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from dataclasses import dataclass
 from typing import Callable, Sequence
@@ -132,17 +133,25 @@ class _GatherWork:
 class HipStepper:
     """Product stepper: the HIP engine on the local array (own rows + ghost rows)."""
 
-    def __init__(self, layout: SlabLayout, params=None, weights=None, dtype="f64", boundary="reference"):
+    def __init__(self, layout: SlabLayout, params=None, weights=None, dtype="f64", boundary="reference",
+                 options=None, variant=None):
         self.plan = ops.Plan(layout.shape, layout.local_dims, params, dtype=dtype)
         if weights is not None:
             self.plan.set_weights(weights)
+        # kernel options / variant come BEFORE the driver fixes its ghost depth: they decide how many applications a
+        # launch fuses (apps_per_launch), which the layout is built around
+        if variant is not None:
+            self.plan.set_variant(variant)
+        for k, v in (options or {}).items():
+            self.plan.set_option(k, int(v))
         if boundary == "dirichlet":
             self.plan.set_boundary(boundary)  # fused launches: intermediate halo cells keep the source's values
         if boundary == "periodic":
             self.plan.set_option("steps_per_launch", 1)  # a fused launch would need the wrap of its inner levels
         # launches go to the stream that is current when the driver is built (looked up once: at 8 GPUs a launch is
         # ~100 us of GPU time, so per-call host work matters)
-        self.stream = int(torch.cuda.current_stream().cuda_stream) if torch.cuda.is_available() else 0
+        self.torch_stream = torch.cuda.current_stream() if torch.cuda.is_available() else None
+        self.stream = int(self.torch_stream.cuda_stream) if self.torch_stream is not None else 0
 
     @property
     def apps_per_launch(self) -> int:
@@ -171,7 +180,7 @@ class SlabDriver:
     def __init__(self, shape, global_dims: Sequence[int], group=None, device=None, params=None, weights=None,
                  stepper_factory: Callable[[SlabLayout], object] | None = None, overlap: bool = True,
                  exchange_every: int | None = None, fused: bool | None = None, boundary_rows: int | None = None,
-                 dtype="f64", boundary: str = "reference", ring_of_one: bool = False):
+                 dtype="f64", boundary: str = "reference", ring_of_one: bool = False, options=None, variant=None):
         if boundary not in ("reference", "dirichlet", "periodic"):
             raise ValueError("boundary must be reference, dirichlet or periodic")
         self.dirichlet = boundary == "dirichlet"
@@ -206,7 +215,8 @@ class SlabDriver:
         self.dtype = ops.dtype_id(dtype)
         self.torch_dtype = torch.bfloat16 if self.dtype == ops.DTYPES["bf16"] else torch.float64
         self._make_stepper = stepper_factory or (
-            lambda lay: HipStepper(lay, params=params, weights=weights, dtype=self.dtype, boundary=boundary))
+            lambda lay: HipStepper(lay, params=params, weights=weights, dtype=self.dtype, boundary=boundary,
+                                   options=options, variant=variant))
         # thinnest slab of the decomposition bounds the ghost depth (neighbours supply ghost rows from own rows)
         thinnest = min(slab_layout(sid, global_dims, self.world_size, r).own for r in range(self.world_size))
         auto_every = exchange_every is None
@@ -257,6 +267,13 @@ class SlabDriver:
         self.valid = layout.ghost  # ghost rows per side that hold the current time level
         self.ring = ["input", "zero"]  # what the halo ring of each physical buffer holds (fused-launch bookkeeping)
 
+    def _on_stream(self):
+        """Everything the driver enqueues -- sweeps, halo-ring copies, the P2P batch and its waits -- must be ordered on
+        ONE stream: the stepper launches on the stream that was current when it was built, while torch copies and
+        `work.wait()` (NCCL: a stream-side wait) act on the stream that is current NOW.  Make them the same."""
+        ts = getattr(self.stepper, "torch_stream", None)
+        return torch.cuda.stream(ts) if ts is not None else contextlib.nullcontext()
+
     # ---- data movement between the global padded array and the slabs ---------------------------------
     def load_global(self, global_padded) -> None:
         """buffer 0 <- this rank's rows of the global padded input (ghost rows and pads included), buffer 1 <- 0."""
@@ -274,23 +291,27 @@ class SlabDriver:
             part = global_padded[lo:hi]
         if isinstance(part, np.ndarray):
             part = torch.from_numpy(np.ascontiguousarray(part))
-        self._flush()
-        self.buf[0].copy_(part.to(self.device))
-        self.buf[1].zero_()
+        with self._on_stream():
+            self._flush()
+            self.buf[0].copy_(part.to(self.device))
+            self.buf[1].zero_()
         self.steps_done, self.cur, self.valid = 0, 0, lay.ghost
         self.ring = ["input", "zero"]
 
     def load_local(self, local_padded: torch.Tensor) -> None:
         """Same from an already-local array (own rows + ghost rows + pads), e.g. generated on the device."""
-        self._flush()
-        self.buf[0].copy_(local_padded)
-        self.buf[1].zero_()
+        with self._on_stream():
+            self._flush()
+            self.buf[0].copy_(local_padded)
+            self.buf[1].zero_()
         self.steps_done, self.cur, self.valid = 0, 0, self.layout.ghost
         self.ring = ["input", "zero"]
 
     def result(self) -> torch.Tensor:
-        """The local padded buffer holding the current time level."""
-        self._flush()
+        """The local padded buffer holding the current time level (its producers are ordered on the stepper's stream:
+        a consumer on another stream synchronises with it first)."""
+        with self._on_stream():
+            self._flush()
         return self.buf[self.cur]
 
     def gather_global(self, dst_rank: int = 0):
@@ -298,10 +319,14 @@ class SlabDriver:
         edge ranks; left/right halos travel with the rows).  Returns a CPU tensor there, None elsewhere."""
         lay = self.layout
         h0 = lay.halo0
-        self._flush()
-        if self.periodic:
-            self.stepper.wrap(self.buf[self.cur])  # the result is a consistent periodic array (like lora_plan_run)
+        with self._on_stream():
+            self._flush()
+            if self.periodic:
+                self.stepper.wrap(self.buf[self.cur])  # the result is a consistent periodic array (like lora_plan_run)
         cur = self.result()
+        ts = getattr(self.stepper, "torch_stream", None)
+        if ts is not None:
+            ts.synchronize()  # the copy to the host below runs on whatever stream is current
         edge_top = self.up is None or (self.periodic and self.rank == 0)
         edge_bottom = self.down is None or (self.periodic and self.rank == self.world_size - 1)
         lo = h0 + lay.ghost_top - (h0 if edge_top else 0)
@@ -379,11 +404,12 @@ class SlabDriver:
 
     def refresh_ghosts(self) -> None:
         """Blocking refresh of the ghost zones of the current buffer (used after loading device-generated data)."""
-        self._flush()
-        if self.up is not None or self.down is not None:
-            for w in self._post_exchange(self.buf[self.cur]):
-                w.wait()
-            self._p2p_worked = True
+        with self._on_stream():
+            self._flush()
+            if self.up is not None or self.down is not None:
+                for w in self._post_exchange(self.buf[self.cur]):
+                    w.wait()
+                self._p2p_worked = True
         self.valid = self.layout.ghost
 
     # ---- one launch (1 or 2 applications) ---------------------------------------------------------------
@@ -465,15 +491,17 @@ class SlabDriver:
 
     def step(self) -> None:
         """One kernel application."""
-        self._launch(False)
+        with self._on_stream():
+            self._launch(False)
 
     def run(self, times: int) -> None:
         """`times` kernel applications (fused pairs where the shape allows, starting at even time levels)."""
         t = 0
-        while t < times:
-            if self.fused and self.steps_done % 2 == 0 and times - t >= self.apps:
-                self._launch(True)
-                t += self.apps
-            else:
-                self._launch(False)
-                t += 1
+        with self._on_stream():
+            while t < times:
+                if self.fused and self.steps_done % 2 == 0 and times - t >= self.apps:
+                    self._launch(True)
+                    t += self.apps
+                else:
+                    self._launch(False)
+                    t += 1

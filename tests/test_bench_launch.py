@@ -1,0 +1,63 @@
+"""bench.py's launch path: `python bench.py --gpus N` must start its own N ranks (the driver's N = 1 form of the command,
+with N > 1) and print ONE JSON line from rank 0.  On a box without a GPU only the plumbing can run
+(`--plumbing-only`: rendezvous + one reduction, value null -- the engine has no CPU path to measure); the same command
+with real sweeps is the GPU test below."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+from conftest import ROOT
+
+
+def _bench(*args, env=None, timeout=600):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, env=e,
+                       timeout=timeout, cwd=ROOT)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, lines
+
+
+def test_bench_starts_its_own_ranks():
+    r, lines = _bench("--gpus", "2", "--steps", "4", "--warmup", "0", "--plumbing-only")
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["plumbing_only"] is True and d["value"] is None
+
+
+def test_planned_launches_follow_the_driver_rule():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    assert bench.planned_launches(1, 100, 8) == (12, 4)   # 1D: 12 eight-step launches + 4 single sweeps
+    assert bench.planned_launches(2, 100, 2) == (50, 0)
+    assert bench.planned_launches(2, 21, 2) == (10, 1)
+    assert bench.planned_launches(2, 3, 2) == (0, 3)       # fewer than 2 K steps: single sweeps only
+    assert bench.planned_launches(2, 20, 1) == (0, 20)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_over_gloo_on_one_gpu():
+    r, lines = _bench("--gpus", "2", "--steps", "4", "--warmup", "0", "--size", "256", "256", "--no-cpu-baseline",
+                      env={"LORA_DIST_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_bench_line_roofline_is_a_fraction():
+    r, lines = _bench("--steps", "8", "--warmup", "2", "--size", "2048", "2048", "--cpu-seconds", "1")
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(lines[-1])
+    rf = d["roofline"]
+    assert d["n_gpus"] == 1 and 0 < rf["frac"] <= 1.0 and rf["applications_per_launch"] == 2
+    assert abs(rf["frac_one_sweep_equiv"] - 2 * rf["frac"]) < 1e-3 and rf["launches"] == 4
+    assert rf["traffic"] is None or rf["traffic_key"].endswith(rf["kernel"])  # never a number of another kernel
+    assert d["cpu_baseline"]["cores"] >= 1

@@ -214,3 +214,32 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h")) or f == "Makefile":
                 text = open(os.path.join(dirpath, f)).read()
                 assert not pat.search(text), f"{os.path.join(dirpath, f)} reaches into oracle/"
+
+
+def test_diagnostics_are_not_in_the_shipped_library(L, monkeypatch):
+    """`ablate` (loads / stores removed: wrong results by construction) exists only in -DLORA_DIAGNOSTICS builds, and no
+    environment variable can swap the engine library."""
+    from lorastencil_amd import _lib
+
+    p = L.Plan("star2d1r", (64, 128))
+    with pytest.raises(L.LoraError) as e:
+        p.set_option("ablate", 1)
+    assert e.value.status == _lib.LORA_EINVAL
+    with pytest.raises(L.LoraError):
+        p.get_option("ablate")
+    src = open(os.path.join(ROOT, "lorastencil_amd", "_lib.py")).read()
+    assert "os.environ" not in src
+    assert _lib.LIB_PATH == os.path.join(ROOT, "lorastencil_amd", "lib", "liblorastencil_hip.so")
+
+
+def test_kernel_signature_names_every_selecting_option(L):
+    p = L.Plan("star2d1r", (16384, 16384))
+    assert p.kernel_signature.startswith(p.kernel_name + "[") and "eval=3" in p.kernel_signature
+    s0 = p.kernel_signature
+    p.set_option("lowrank_valu", 0)
+    assert p.kernel_signature != s0  # another instantiation: measured traffic filed under s0 no longer applies
+    p.set_option("stream", 1)
+    assert p.kernel_name == "stencil2d_stream2_kernel" and "depth=" in p.kernel_signature and "rows=" in p.kernel_signature
+    assert L.Plan("1d1r", (4096,)).kernel_signature == "stencil1d_fusedk_kernel[k=8]"
+    with pytest.raises(L.LoraError):
+        L.Plan("1d1r", (2**31 - 9,))  # padded extent would overflow the kernels' 32-bit indices
