@@ -165,8 +165,9 @@ def self_launch(args) -> int:
 
 
 def planned_launches(ndim, times, spl, fused_ok=True):
-    """(fused launches, single-sweep launches) of one run: the rule of run_launches() in csrc/capi.cpp -- an even
-    number of K-application launches while at least 2 K steps remain, then single sweeps."""
+    """(K-application launches, single-sweep launches) of one run: the rule of run_launches() in csrc/capi.cpp -- an
+    even number of K-application launches while at least 2 K steps remain, then single sweeps.  (2D with K = 4 also
+    uses two-application launches for the tail: that schedule is reported by lora_plan_run_profiled itself.)"""
     if spl < 2 or not fused_ok or times < 2 * spl:
         return 0, times
     pairs = (times // spl) & ~1

@@ -167,11 +167,12 @@ int lora_plan_set_boundary(lora_plan *plan, int boundary);
  * (what the CLIs' --bc flag sets).  Returns the previous value. */
 int lora_set_default_boundary(int boundary);
 /* Integer options.  Results never depend on them except where stated.
- *   steps_per_launch  0 auto / 1 / 2 (1D also 4, 8) : applications per launch in lora_plan_run (temporal fusion;
- *                     default 2 for every tiled 2D and 3D plan, fp64 and bf16, and 8 in 1D)
+ *   steps_per_launch  0 auto / 1 / 2 (2D also 4 with the row-streaming kernel, 1D also 4, 8) : applications per launch
+ *                     in lora_plan_run (temporal fusion)
  *   rows_per_thread, panel_width, nt_store, fused_rows, persistent      2D tile shape / block->tile map / stores
- *   lowrank_valu      -1 auto / 0 / 1 / 2, 3 (plain / symmetric pyramid form) : low-rank evaluation inside the fused 2D kernel (summation order changes:
- *                     identical while values are exact integers, ~1 ulp afterwards)
+ *   lowrank_valu      -1 auto / 0 off / 1 on / 2, 3 (plain / symmetric pyramid form) / 4 (rank-1 + correction instead of the
+ *                     nested-profile form) : structured evaluation of the taps inside the fused 2D kernels (summation
+ *                     order changes: identical while values are exact integers, ~1 ulp afterwards)
  *   z_chunk, fused_z_chunk             3D output planes per workgroup (single-sweep / fused kernels; 0 = auto)
  *   separable         -1 auto / 0     bf16: exactly separable taps as x/y/z passes (changes the fp32 summation
  *                     order; the oracle restates both orders, see lora_separable_3x3x3)
@@ -228,11 +229,13 @@ int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *
  * the very region it timed (bench.py's roofline).  Launches directly (no hipGraph) and BLOCKS until the run has
  * finished.  Halo bookkeeping kernels (O(surface)) are inside the fused segment. */
 typedef struct lora_run_profile {
-    int fused_launches;        /* launches of the K-application kernel            */
-    int apps_per_fused_launch; /* K (1 if the plan does not fuse)                 */
-    int single_launches;       /* single-sweep launches (the whole run if K = 1)  */
-    float fused_ms;            /* event time of the fused segment                 */
-    float single_ms;           /* event time of the single-sweep segment          */
+    int fused_launches;        /* launches of the K-application kernel                               */
+    int apps_per_fused_launch; /* K (1 if the plan does not fuse)                                    */
+    int two_launches;          /* 2D, K = 4: two-application launches that take the tail of the run  */
+    int single_launches;       /* single-sweep launches (the whole run if K = 1)                     */
+    float fused_ms;            /* event time of the K-application launches (+ the halo copy)         */
+    float two_ms;              /* ... of the two-application tail (+ the halo reset)                 */
+    float single_ms;           /* ... of the single-sweep segment                                    */
 } lora_run_profile;
 int lora_plan_run_profiled(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream,
                            lora_run_profile *profile);

@@ -54,8 +54,10 @@ class RunProfile(ctypes.Structure):
     _fields_ = [
         ("fused_launches", ctypes.c_int),
         ("apps_per_fused_launch", ctypes.c_int),
+        ("two_launches", ctypes.c_int),
         ("single_launches", ctypes.c_int),
         ("fused_ms", ctypes.c_float),
+        ("two_ms", ctypes.c_float),
         ("single_ms", ctypes.c_float),
     ]
 

@@ -171,13 +171,17 @@ void plan_refresh(Plan &p) {
         if (p.variant == LORA_VARIANT_MFMA || p.generic)
             p.steps_per_launch = 1;
         else
-            p.steps_per_launch = p.steps_per_launch_req == 0 ? 2 : p.steps_per_launch_req;
+            p.steps_per_launch = p.steps_per_launch_req == 0 ? 4 : p.steps_per_launch_req;
+        // Temporal fusion wins for every tap set: star2d1r 16384^2 352 (one sweep per launch) -> 593 (tile kernel, 2)
+        // -> 591 (row-streaming, 2) -> 843 GStencils/s (row-streaming, 4: profiles/r02_*).  Four applications per launch exist in the row-streaming kernel, reference boundary (the level-2 halo is the
+        // source buffer's own; the Dirichlet option would need source rows 11 steps back)
+        if (p.steps_per_launch == 4 && !(p.stream2 && p.boundary == LORA_BC_REFERENCE)) p.steps_per_launch = 2;
         p.fused_rows = p.fused_rows_req ? p.fused_rows_req : (p.tapset == TAPS2D_STAR ? 6 : 10);
         // Low-rank evaluation on the vector pipe inside the fused kernel (kernels_2d_fused.hip, apply_row): taken
         // when the factors have the support pattern one of its two forms is specialised for.
         p.fused_eval = p.tapset;
         p.lowrank_rc = 0.0;
-        if (p.lowrank_valid && p.lowrank_valu != 0 && p.steps_per_launch == 2) {
+        if (p.lowrank_valid && p.lowrank_valu != 0 && p.steps_per_launch >= 2) {
             const LowRank2D &lr = p.lowrank;
             auto outside_zero = [&](int t, int lo) {
                 for (int e = 0; e < 7; ++e)
@@ -215,10 +219,45 @@ void plan_refresh(Plan &p) {
                 }
             }
         }
+        // Nested-profile form (rows_2d.h, EVAL_NEST): row dy of the table = g[k] T_k, k = 3 - |dy - 3|, T_0 = x3,
+        // T_k = a_k T_(k-1) + (x_(3-k) + x_(3+k)).  Accepted only if the taps it implies are the plan's taps EXACTLY.
+        if (p.lowrank_valu != 0 && p.lowrank_valu != 4 && p.steps_per_launch >= 2) {
+            const double *W = p.w;
+            double g[4], a[4] = {0, 0, 0, 0};
+            bool ok = true;
+            for (int k = 0; k < 4 && ok; ++k) {
+                g[k] = W[k * 7 + (3 - k)];  // outermost tap of row k
+                if (!(g[k] != 0.0) || !std::isfinite(g[k])) ok = false;
+            }
+            for (int k = 1; k < 4 && ok; ++k) {
+                a[k] = W[k * 7 + (4 - k)] / g[k];  // next tap inwards / outermost tap
+                if (!std::isfinite(a[k])) ok = false;
+            }
+            for (int dy = 0; dy < 7 && ok; ++dy) {
+                const int k = dy <= 3 ? dy : 6 - dy;
+                // coefficient of x_(3 +- e) in T_k: prod of a_j for j = e+1 .. k (1 for e = k, absent for e > k)
+                for (int dx = 0; dx < 7; ++dx) {
+                    const int e = dx <= 3 ? 3 - dx : dx - 3;
+                    double c = 0.0;
+                    if (e <= k) {
+                        c = g[k];
+                        for (int j2 = k; j2 > e; --j2) c *= a[j2];
+                    }
+                    if (c != W[dy * 7 + dx]) ok = false;
+                }
+            }
+            if (ok) {
+                p.fused_eval = 7;
+                for (int k = 0; k < 4; ++k) {
+                    p.nest_g[k] = g[k];
+                    p.nest_a[k] = a[k];
+                }
+            }
+        }
         p.kernel_name = p.generic ? kernel_name_generic(p)
                         : (p.variant == LORA_VARIANT_MFMA)
                             ? kernel_name_2d_mfma(p)
-                            : (p.steps_per_launch == 2 ? (p.stream2 ? kernel_name_2d_stream2(p) : kernel_name_2d_fused2(p))
+                            : (p.steps_per_launch >= 2 ? (p.stream2 ? kernel_name_2d_stream(p) : kernel_name_2d_fused2(p))
                                                        : kernel_name_2d_direct(p));
     } else if (p.ndim == 3) {
         bool star = true;
@@ -347,7 +386,7 @@ int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, con
         return LORA_EUNSUPPORTED;
     }
     if ((double) lora_padded_count(shape, dims) >= 2147483647.0 * 64) return LORA_EUNSUPPORTED;
-    if (nd == 1 && dims[0] > 2147483647 - 4096) {
+    if (nd == 1 && dims[0] > 2147483647 - 8) {
         g_last_error = "1D extent too large (kernels index the padded array with 32-bit integers)";
         return LORA_EUNSUPPORTED;
     }
@@ -420,7 +459,7 @@ int lora_plan_set_boundary(lora_plan *plan, int boundary) {
             }
     }
     plan->p.boundary = boundary;
-    ++plan->p.epoch;
+    lora::plan_refresh(plan->p);  // the boundary option decides how many applications a launch may fuse
     return LORA_OK;
 }
 
@@ -463,12 +502,14 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         if (value < 2 || value > 6) return LORA_EINVAL;
         p.stream_depth = value;
     } else if (!std::strcmp(key, "stream_sync")) {
-        p.stream_sync = value ? 1 : 0;
+        if (value < 0 || value > 2) return LORA_EINVAL;
+        p.stream_sync = value;
     } else if (!std::strcmp(key, "graph")) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.use_graph = value;
     } else if (!std::strcmp(key, "lowrank_valu")) {
-        if (value < -1 || value > 3) return LORA_EINVAL;  // 2 / 3: plain / symmetric pyramid form (A/B timing)
+        if (value < -1 || value > 4) return LORA_EINVAL;  // 2 / 3: plain / symmetric pyramid form, 4: rank-1 + correction
+                                                           // instead of the nested-profile form (A/B timing)
         p.lowrank_valu = value;
     } else if (!std::strcmp(key, "separable")) {
         if (value < -1 || value > 1) return LORA_EINVAL;
@@ -493,7 +534,8 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         const bool fusable = (p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && !p.generic) ||
                              (p.ndim == 3 && !p.generic) || p.ndim == 1;
         if (value >= 2 && !fusable) return LORA_EUNSUPPORTED;
-        if (value > 2 && p.ndim != 1) return LORA_EUNSUPPORTED;  // 2D / 3D kernels fuse two applications
+        if (value > 2 && p.ndim == 3) return LORA_EUNSUPPORTED;  // 3D kernels fuse two applications
+        if (value > 4 && p.ndim == 2) return LORA_EUNSUPPORTED;  // 2D: two, or four in the row-streaming kernel
         p.steps_per_launch_req = value;
     } else if (!std::strcmp(key, "fused_pipeline")) {
         p.fused_pipeline = value ? 1 : 0;
@@ -573,10 +615,12 @@ const char *lora_plan_kernel_signature(const lora_plan *plan) {
     char buf[256];
     const std::string &k = p.kernel_name;
     buf[0] = 0;
-    if (k == "stencil2d_stream2_kernel")
-        std::snprintf(buf, sizeof buf, "eval=%d,depth=%d,sync=%d,rows=%d,bc=%d", p.fused_eval,
-                      p.boundary == LORA_BC_DIRICHLET ? 4 : p.stream_depth, p.stream_sync,
-                      lora::stream2_rows_per_chunk(p, p.dims[0], (p.dims[1] + 115) / 116), p.boundary);
+    if (k == "stencil2d_stream_kernel") {
+        const int K = p.steps_per_launch, w = lora::stream_strip_width(K);
+        const int depth = p.boundary == LORA_BC_DIRICHLET ? 4 : (K == 4 ? (p.stream_depth == 2 ? 2 : 3) : p.stream_depth);
+        std::snprintf(buf, sizeof buf, "eval=%d,k=%d,depth=%d,sync=%d,rows=%d,bc=%d", p.fused_eval, K, depth,
+                      p.stream_sync, lora::stream_rows_per_chunk(p, K, p.dims[0], (p.dims[1] + w - 1) / w), p.boundary);
+    }
     else if (k == "stencil2d_fused2_kernel")
         std::snprintf(buf, sizeof buf, "eval=%d,rows=%d,persist=%d,panel=%d,bc=%d", p.fused_eval, p.fused_rows,
                       p.persistent, p.panel_width, p.boundary);
@@ -616,9 +660,12 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
     if (!ok2 && !ok3) return LORA_EUNSUPPORTED;
     if (int rc = lora::check_buffers(d_in, d_out)) return rc;
     if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
-    const hipError_t e = ok2 ? (p.stream2 ? lora::launch_2d_stream2 : lora::launch_2d_fused2)(
-                                   p, static_cast<const double *>(d_in), static_cast<double *>(d_out), begin, end,
-                                   static_cast<hipStream_t>(stream))
+    const hipError_t e = ok2 ? (p.stream2 ? lora::launch_2d_stream(p, 2, static_cast<const double *>(d_in),
+                                                                   static_cast<double *>(d_out), begin, end,
+                                                                   static_cast<hipStream_t>(stream))
+                                          : lora::launch_2d_fused2(p, static_cast<const double *>(d_in),
+                                                                   static_cast<double *>(d_out), begin, end,
+                                                                   static_cast<hipStream_t>(stream)))
                          : p.dtype == LORA_BF16
                              ? lora::launch_3d_bf16_fused2(p, d_in, d_out, begin, end, static_cast<hipStream_t>(stream))
                              : lora::launch_3d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),
@@ -658,6 +705,17 @@ int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int b
     if (!plan) return LORA_EINVAL;
     Plan &p = plan->p;
     if (p.steps_per_launch <= 1) return lora_plan_step_region(plan, d_in, d_out, begin, end, stream);
+    if (p.ndim == 2 && p.steps_per_launch == 4) {
+        if (int rc = lora::check_buffers(d_in, d_out)) return rc;
+        if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
+        const hipError_t e = lora::launch_2d_stream(p, 4, static_cast<const double *>(d_in), static_cast<double *>(d_out),
+                                                    begin, end, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) {
+            lora::set_last_error("fused 4-step kernel launch", e);
+            return LORA_EHIP;
+        }
+        return LORA_OK;
+    }
     if (p.ndim != 1) return lora_plan_step2_region(plan, d_in, d_out, begin, end, stream);
     if (int rc = lora::check_buffers(d_in, d_out)) return rc;
     if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end || (begin & 1)) return LORA_EINVAL;
@@ -677,8 +735,8 @@ int lora_plan_stepk(lora_plan *plan, const void *d_in, void *d_out, void *stream
 
 // The launches of one run, in order, on `stream` (also what gets captured into a hipGraph).
 struct RunMarks {  // lora_plan_run_profiled: events around the fused and the single-sweep segment
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    int fused_launches = 0, single_launches = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start | K-launches | 2-launches | singles
+    int fused_launches = 0, two_launches = 0, single_launches = 0;
 };
 
 static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream, RunMarks *marks = nullptr) {
@@ -692,6 +750,7 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
     if (times == 0) {
         mark(1);
         mark(2);
+        mark(3);
         return LORA_OK;
     }
     auto halo = [&](void *dst, const void *src, int mode, const char *what) -> int {
@@ -711,13 +770,14 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
         // end so that the result is a consistent periodic array (single sweeps: a fused launch would need the wrap
         // of its intermediate level)
         mark(1);
+        mark(2);
         for (int i = 0; i < times; ++i) {
             if (int rc = halo(buf[i % 2], nullptr, lora::HALO_WRAP, "periodic halo")) return rc;
             if (int rc = lora_plan_step(plan, buf[i % 2], buf[(i + 1) % 2], stream)) return rc;
         }
         if (marks) marks->single_launches = times;
         const int rc = halo(buf[times % 2], nullptr, lora::HALO_WRAP, "periodic halo");
-        mark(2);
+        mark(3);
         return rc;
     }
 
@@ -730,32 +790,49 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
     const int K = p.steps_per_launch;  // applications per fused launch: 2 (2D, 3D) or 2 / 4 / 8 (1D)
     const bool can_fuse = K >= 2 && !p.generic &&
                           ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) || p.ndim == 3 || p.ndim == 1);
-    if (can_fuse && times >= 2 * K) {
+    if (can_fuse && (times >= 2 * K || (p.ndim == 2 && K == 4 && times >= 4))) {
         // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes the other one,
         // so while fused launches run BOTH physical buffers carry buffer 0's halo; an even number of them leaves
         // the data in buffer 0, after which (reference boundary) buffer 1's halo is put back to 0 and the remaining
         // 0..3 steps are single sweeps -- the result and its halo end up exactly where the step-by-step driver
         // leaves them.  With the Dirichlet boundary both halos simply stay.
         if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
-        const int pairs = (times / K) & ~1;
+        int pairs = (times / K) & ~1;
+        int twos = 0;  // 2D, K = 4: two-application launches take the tail, so that at most one single sweep remains
+        if (p.ndim == 2 && K == 4) {
+            pairs = times / 4;
+            twos = (times - 4 * pairs) / 2;
+            if ((pairs + twos) & 1) {  // the data must end up in buffer 0: an even number of fused launches
+                pairs -= 1;
+                twos += 2;
+            }
+        }
         if (!dirichlet)
             if (int rc = halo(buf[1], buf[0], lora::HALO_COPY, "halo copy")) return rc;
         for (int k = 0; k < pairs; ++k) {
             const int rc = lora_plan_stepk(plan, buf[k % 2], buf[(k + 1) % 2], stream);
             if (rc != LORA_OK) return rc;
         }
+        mark(1);
+        for (int k = pairs; k < pairs + twos; ++k) {
+            const int rc = lora_plan_step2(plan, buf[k % 2], buf[(k + 1) % 2], stream);
+            if (rc != LORA_OK) return rc;
+        }
         if (!dirichlet)
             if (int rc = halo(buf[1], nullptr, lora::HALO_ZERO, "halo reset")) return rc;
-        done = K * pairs;
+        done = K * pairs + 2 * twos;
         if (marks) marks->fused_launches = pairs;
+        if (marks) marks->two_launches = twos;
+    } else {
+        mark(1);
     }
-    mark(1);
+    mark(2);
     for (int i = done; i < times; ++i) {  // 2d/gpu.cu:544-546
         const int rc = lora_plan_step(plan, buf[i % 2], buf[(i + 1) % 2], stream);
         if (rc != LORA_OK) return rc;
     }
     if (marks) marks->single_launches = times - done;
-    mark(2);
+    mark(3);
     return LORA_OK;
 }
 
@@ -837,12 +914,14 @@ int lora_plan_run_profiled(lora_plan *plan, void *d_buf0, void *d_buf1, int time
     for (hipEvent_t &e : marks.ev) LORA_HIP_TRY(hipEventCreate(&e));
     const int rc = run_launches(plan, d_buf0, d_buf1, times, stream, &marks);
     if (rc != LORA_OK) return rc;
-    LORA_HIP_TRY(hipEventSynchronize(marks.ev[2]));
+    LORA_HIP_TRY(hipEventSynchronize(marks.ev[3]));
     profile->fused_launches = marks.fused_launches;
     profile->apps_per_fused_launch = marks.fused_launches ? plan->p.steps_per_launch : 1;
+    profile->two_launches = marks.two_launches;
     profile->single_launches = marks.single_launches;
     LORA_HIP_TRY(hipEventElapsedTime(&profile->fused_ms, marks.ev[0], marks.ev[1]));
-    LORA_HIP_TRY(hipEventElapsedTime(&profile->single_ms, marks.ev[1], marks.ev[2]));
+    LORA_HIP_TRY(hipEventElapsedTime(&profile->two_ms, marks.ev[1], marks.ev[2]));
+    LORA_HIP_TRY(hipEventElapsedTime(&profile->single_ms, marks.ev[2], marks.ev[3]));
     return LORA_OK;
 }
 

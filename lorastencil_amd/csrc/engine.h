@@ -63,19 +63,20 @@ struct Plan {
     int ablate = 0;           // diagnostics only (2D fused, 3D bf16): 1 = skip stores, 2 = skip loads; results wrong
     int lds_dma = 0;          // 3D bf16: global_load_lds ring, two planes ahead (hand-counted vmcnt)
     int persistent = 0;       // 2D fused: persistent workgroups with register prefetch of the next tile
-    int stream2 = 0;          // 2D fused: row-streaming kernel (kernels_2d_stream.hip) instead of the tile kernel
+    int stream2 = 1;          // 2D fused: row-streaming kernel (kernels_2d_stream.hip, default) or the tile kernel (0)
     int stream_rows = 0;      // ... output rows per chunk (0 = auto: whole rounds of resident waves)
-    int stream_depth = 4;     // ... input rows in flight per wave (2..6)
-    int stream_sync = 1;      // ... one s_barrier per 7 rows keeps a workgroup's four strips in step
+    int stream_depth = 4;     // ... input rows in flight per wave (2..6; at most 3 with four applications per launch)
+    int stream_sync = 1;      // ... s_barrier per 7 rows (1) / per row (2) keeps a workgroup's four strips in step
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
     int fused_pipeline = 0;   // 3D bf16 fused: 1 = level 2 one plane behind level 1, one barrier per plane (no gain measured)
     int fused_z_chunk = 0;    // 3D fused: output planes per workgroup (0 = auto: 32, shorter on small grids)
-    int steps_per_launch_req = 0;  // 0 = auto, 1, 2 (2D / 3D), 2 / 4 / 8 (1D)
+    int steps_per_launch_req = 0;  // 0 = auto, 1, 2 (2D / 3D), 4 (2D row-streaming kernel), 2 / 4 / 8 (1D)
     int steps_per_launch = 1;      // resolved
     bool generic = false;  // odd innermost extent: rows are only 8-byte aligned, the tiled kernels do not apply
     int lowrank_valu = -1;    // 2D fused: low-rank evaluation on the vector pipe: -1 auto, 0 off, 1 on when the factors fit
-    int fused_eval = 0;       // resolved: 0 = direct taps of `tapset`, 3 = low-rank diamond, 4 = low-rank pyramid
+    int fused_eval = 0;       // resolved: 0..2 = direct taps of `tapset`, 3 = low-rank diamond, 4..6 = low-rank pyramid forms, 7 = nested profiles
     double lowrank_rc = 0.0;  // weight of the diamond form's 8-point correction
+    double nest_g[4] = {0, 0, 0, 0}, nest_a[4] = {0, 0, 0, 0};  // fused_eval 7: nested-profile form (rows_2d.h)
     bool lowrank_valid = false;
     LowRank2D lowrank{};
     std::string kernel_name;
@@ -101,9 +102,11 @@ enum HaloMode { HALO_COPY = 0, HALO_ZERO = 1, HALO_WRAP = 2 };
 hipError_t launch_halo(const Plan &p, void *dst, const void *src, int mode, hipStream_t s);
 const char *kernel_name_2d_fused2(const Plan &p);
 // the same two applications per launch, row-streaming form (wave-autonomous column strips)
-hipError_t launch_2d_stream2(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
-const char *kernel_name_2d_stream2(const Plan &p);
-int stream2_rows_per_chunk(const Plan &p, int rows_total, int strips);  // resolved chunk height of a launch
+// (K = 2 or 4 applications per launch)
+hipError_t launch_2d_stream(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s);
+const char *kernel_name_2d_stream(const Plan &p);
+int stream_rows_per_chunk(const Plan &p, int K, int rows_total, int strips);  // resolved chunk height of a launch
+int stream_strip_width(int K);
 hipError_t launch_3d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 // two applications per launch, level 1 in LDS (fp64, reference boundary: level-1 halo = 0)
 hipError_t launch_3d_fused2(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);

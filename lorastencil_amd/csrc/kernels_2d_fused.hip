@@ -257,6 +257,11 @@ hipError_t launch_fused2_t(const Plan &p, const double *in, double *out, int beg
             f.v[t][e] = p.lowrank.v[t][e];
         }
     f.rc = p.lowrank_rc;
+    if (TAPSET == EVAL_NEST)
+        for (int k = 0; k < 4; ++k) {
+            f.u[0][k] = p.nest_g[k];
+            f.v[0][k] = p.nest_a[k];
+        }
     const long nblocks = (long) a.tiles_x * a.tiles_y;
     if (nblocks <= 0) return hipSuccess;
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
@@ -280,6 +285,7 @@ hipError_t launch_fused2_t(const Plan &p, const double *in, double *out, int beg
 
 hipError_t launch_2d_fused2(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
 #define LORA_FUSED_DISPATCH(R1)                                                        \
+    if (p.fused_eval == EVAL_NEST) return launch_fused2_t<EVAL_NEST, R1>(p, in, out, begin, end, s); \
     if (p.fused_eval == EVAL_LR_DIAMOND) return launch_fused2_t<EVAL_LR_DIAMOND, R1>(p, in, out, begin, end, s); \
     if (p.fused_eval == EVAL_LR_PYRAMID) return launch_fused2_t<EVAL_LR_PYRAMID, R1>(p, in, out, begin, end, s); \
     if (p.fused_eval == EVAL_LR_PYRAMID_SYM) return launch_fused2_t<EVAL_LR_PYRAMID_SYM, R1>(p, in, out, begin, end, s); \

@@ -38,11 +38,16 @@ namespace lora {
 
 namespace {
 
-constexpr int kSOutW = 116;  // output columns per strip (58 lanes x 2)
 constexpr int kSInW = 128;   // input columns per strip: one 16-byte piece per lane
-constexpr int kSlots = 7;    // input-row ring slots per wave (= the unroll factor, so slot = phase)
-constexpr int kBRow = 136;   // doubles of the intermediate row buffer (lanes past 60 read slack)
-constexpr int kWaveLds = kSlots * kSInW + kBRow;  // doubles of LDS per wave
+constexpr int kBRow = 136;   // doubles of an intermediate row buffer (lanes past the valid range read slack)
+
+// K applications per launch: every level shifts the lane -> column map by 3, so a strip yields 128 - 6 K output columns
+// (116 for K = 2, 104 for K = 4) from its 128 input columns.
+__host__ __device__ constexpr int stream_out_w(int K) { return kSInW - 6 * K; }
+// Input-row ring slots per wave.  K = 2: seven, so that slot = step mod 7 is a compile-time constant of the 7-fold
+// unrolled loop.  K = 4: ten (run-time slot index): the level-2 rows need the input row of 7 steps ago, see below.
+__host__ __device__ constexpr int stream_slots(int K) { return K == 2 ? 7 : 10; }
+__host__ __device__ constexpr int stream_wave_lds(int K) { return stream_slots(K) * kSInW + (K - 1) * kBRow; }
 
 struct ArgsStream {
     const double *in;
@@ -51,24 +56,38 @@ struct ArgsStream {
     int row_begin, row_end;
     int strips;     // column strips
     int chunks;     // row chunks of the launch
-    int rows;       // output rows per chunk: 7 groups - 6
-    int groups;     // main-loop groups of 7 steps per chunk
-    int dirichlet;  // intermediate cells outside the interior keep the input halo value instead of 0
+    int rows;       // output rows per chunk: 7 groups - 7 K + 1
+    int groups;     // groups of 7 steps per chunk
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-// D = input rows in flight per wave (1..6; <= 4 under the Dirichlet option, which re-reads the row 3 steps back);
-// SYNC = one s_barrier per 7 rows keeps the four strips of a workgroup in step (L1 / L2 hits on their shared columns).
-template <int EVAL, int D, int SYNC, bool DIRI>
-__global__ __launch_bounds__(256, 4) void stencil2d_stream2_kernel(const ArgsStream a, const Taps49 W, const LowRankTaps F) {
-    static_assert(D >= 1 && D <= 6, "rows in flight");
-    __shared__ __attribute__((aligned(16))) double lds[4 * kWaveLds];
+// Step r of a chunk whose first output row is i0 consumes input row i0 - 3 K + r and completes, for l = 1..K, the
+// level-l row  i0 - 3 K - 4 l + 1 + r  (level l lags 3 rows -- its radius -- plus one step of hand-off behind level
+// l - 1: a level's row is written to its LDS row buffer in one step and picked up by the next level in the following
+// step, which lets one step run the K levels top down with ONE window in registers at a time).  Level K is the output.
+//
+// Cells of an intermediate level outside the interior are halo cells of the reference driver's buffers:
+// never written, so 0 at odd levels (buffer 1) and the source buffer's own halo value at even levels (buffer 0) --
+// or the source value at every level under the Dirichlet option (DIRI; K = 2 only).  The source value of a level-l
+// cell is the same cell of the input row consumed 4 l - 1 steps earlier: still in the ring for (K = 2, l = 1, D <= 4)
+// and for (K = 4, l = 2, ten slots, D <= 3).
+//
+// D = input rows in flight per wave; SYNC = 1: one s_barrier per 7 rows keeps the four strips of a workgroup in step
+// (L2 hits on their shared columns), 2: one per row (L1 hits).
+template <int EVAL, int K, int D, int SYNC, bool DIRI>
+__global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel(const ArgsStream a, const Taps49 W, const LowRankTaps F) {
+    constexpr int NS = stream_slots(K);
+    constexpr int OUTW = stream_out_w(K);
+    constexpr int WLDS = stream_wave_lds(K);
+    static_assert(K == 2 || K == 4, "applications per launch");
+    static_assert(D >= 2 && D <= 6 && (K == 2 || D <= 3) && (!DIRI || (K == 2 && D <= 4)), "rows in flight");
+    __shared__ __attribute__((aligned(16))) double lds[4 * WLDS];
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *const A = lds + wv * kWaveLds;  // ring: slot s = input row (step) s mod 7
-    double *const B = A + kSlots * kSInW;   // the intermediate row being handed from level 1 to level 2
+    double *const A = lds + wv * WLDS;  // ring: slot s = input row (step) s mod NS
+    double *const B = A + NS * kSInW;   // B + (l - 1) kBRow: the level-l row handed to level l + 1
 
     // wave -> (chunk, strip): consecutive waves take consecutive strips of one chunk; waves past the end of the
     // launch (last workgroup only) run the same instruction stream on the last strip with every store switched off
@@ -78,30 +97,38 @@ __global__ __launch_bounds__(256, 4) void stencil2d_stream2_kernel(const ArgsStr
     const int wl = spare ? total - 1 : wlin;
     const int chunk = wl / a.strips, strip = wl - chunk * a.strips;
     const int i0 = a.row_begin + chunk * a.rows;  // first output row of the chunk (interior coordinates)
-    const int j0 = strip * kSOutW;                // first output column of the strip
+    const int j0 = strip * OUTW;                  // first output column of the strip
     const int row_hi = spare ? i0 : min(i0 + a.rows, a.row_end);
 
-    // step r consumes input row i0 - 6 + r = padded row i0 - 2 + r, padded columns j0 - 2 + 2 lane, +1 (clamped into
-    // the padded array: clamped pieces only feed intermediate cells outside the interior, which are forced below)
-    const int gcol = min(max(j0 - 2 + 2 * lane, 0), a.n + 6);
+    // input: interior columns j0 - 3 K + 2 lane, +1 = padded columns j0 - 3 K + 4 + 2 lane (clamped into the padded
+    // array: clamped pieces only feed intermediate cells outside the interior, which are forced below)
+    const int gcol = min(max(j0 - 3 * K + 4 + 2 * lane, 0), a.n + 6);
     const double *const in_lane = a.in + gcol;
     auto issue = [&](int r, int slot) {
-        const int pr = min(max(i0 - 2 + r, 0), a.m + 7);
+        const int pr = min(max(i0 - 3 * K + 4 + r, 0), a.m + 7);
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (in_lane + (size_t) pr * a.ld),
                                          (__attribute__((address_space(3))) void *) (A + slot * kSInW), 16, 0, 0);
     };
-    // intermediate columns of this lane: interior columns j0 - 3 + 2 lane, +1
-    const int jm = j0 - 3 + 2 * lane;
-    const bool c0_in = jm >= 0 && jm < a.n;
-    const bool c1_in = jm + 1 >= 0 && jm + 1 < a.n;
-    // stores: lanes 0..57 write interior columns j0 + 2 lane, +1; the descriptor's range check drops the rest
-    const unsigned store_off = lane < kSOutW / 2 ? 16u * lane : 0x80000000u;
-    const unsigned row_bytes = (unsigned) (min(kSOutW, a.n - j0) * 8);
+    // level-l columns of this lane: interior columns j0 - 3 K + 3 l + 2 lane, +1
+    bool cin0[K], cin1[K];
+#pragma unroll
+    for (int l = 1; l < K; ++l) {
+        const int jl = j0 - 3 * K + 3 * l + 2 * lane;
+        cin0[l] = jl >= 0 && jl < a.n;
+        cin1[l] = jl + 1 >= 0 && jl + 1 < a.n;
+    }
+    // stores: lanes 0 .. OUTW/2 - 1 write interior columns j0 + 2 lane, +1; the descriptor's range check drops the rest
+    const unsigned store_off = lane < OUTW / 2 ? 16u * lane : 0x80000000u;
+    const unsigned row_bytes = (unsigned) (min(OUTW, a.n - j0) * 8);
     double *const out_strip = a.out + (j0 + 4);
 
-    double p1a[7], p1b[7], p2a[7], p2b[7];  // rotating partial sums of the two levels, columns 2 lane / 2 lane + 1
+    double pa[K][7], pb[K][7];  // rotating partial sums of the K levels, columns 2 lane / 2 lane + 1
 #pragma unroll
-    for (int k = 0; k < 7; ++k) p1a[k] = p1b[k] = p2a[k] = p2b[k] = 0.0;
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+        for (int k = 0; k < 7; ++k) pa[l][k] = pb[l][k] = 0.0;
+#pragma unroll
+    for (int l = 0; l < K - 1; ++l) *reinterpret_cast<d2 *>(B + l * kBRow + 2 * lane) = (d2){0.0, 0.0};
 
     // vector-memory stream: L(0), then per step exactly { store, L(r + D) }: D - 1 dummy { store, load } pairs up front
     // make "younger than L(r)" the same 2 (D - 1) operations at every step
@@ -116,98 +143,130 @@ __global__ __launch_bounds__(256, 4) void stencil2d_stream2_kernel(const ArgsStr
     const double *const winA = A + 2 * lane;
     const double *const winB = B + 2 * lane;
 
-    auto step = [&](const int r, auto phase_tag, auto full_tag) {
-        constexpr int P = decltype(phase_tag)::value;     // r mod 7 = ring slot of input row r
-        constexpr bool FULL = decltype(full_tag)::value;  // level 2 runs from step 7 on
-        constexpr int Q = (P + 6) % 7;                    // (r - 1) mod 7
+    // sl = ring slot of input row r (= phase when NS == 7)
+    auto step = [&](const int r, const int sl, auto phase_tag) {
+        constexpr int P = decltype(phase_tag)::value;  // r mod 7
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
-        // ---- level 1: input row r into the intermediate rows r .. r+6 (tap row 6 - k of row r + k) ----
-        {
-            d2 wa[4];
+        if (SYNC == 2) __builtin_amdgcn_s_barrier();
+        auto wrap = [](int x) { return x >= NS ? x - NS : x; };
+        // ---- levels K .. 2: the level-(l-1) row completed in the previous step, from its row buffer ----
 #pragma unroll
-            for (int q = 0; q < 4; ++q) wa[q] = *reinterpret_cast<const d2 *>(winA + P * kSInW + 2 * q);
+        for (int l = K; l >= 2; --l) {
+            const int R = (P + 7 * K - (l - 1)) % 7;  // (r - (l - 1)) mod 7: the rotation this level is at
             double win[8];
+            {
+                d2 w4[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                win[2 * q] = wa[q].x;
-                win[2 * q + 1] = wa[q].y;
+                for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const d2 *>(winB + (l - 2) * kBRow + 2 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    win[2 * q] = w4[q].x;
+                    win[2 * q + 1] = w4[q].y;
+                }
             }
-            apply_row<EVAL, 7, P>(6, win, p1a, p1b, W, F);
+            // R is a compile-time constant after unrolling; dispatch it to the template parameter
+            auto run = [&](auto rot_tag) {
+                constexpr int ROT = decltype(rot_tag)::value;
+                apply_row<EVAL, 7, ROT>(6, win, pa[l - 1], pb[l - 1], W, F);
+                d2 v;
+                v.x = pa[l - 1][ROT];
+                v.y = pb[l - 1][ROT];
+                pa[l - 1][ROT] = 0.0;
+                pb[l - 1][ROT] = 0.0;
+                const int row = i0 - 3 * K - 4 * l + 1 + r;  // interior row of the completed level-l row
+                if (l == K) {
+                    const bool live = row >= i0 && row < row_hi;
+                    const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+                        out_strip + (size_t) (max(row, 0) + 4) * a.ld, 0, live ? row_bytes : 0u, 0x00020000);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, store_off, 0, 0);
+                } else {
+                    const bool row_in = row >= 0 && row < a.m;
+                    const bool in0 = row_in && cin0[l], in1 = row_in && cin1[l];
+                    if ((l & 1) == 0 || DIRI) {
+                        // halo cell of an even level: the source buffer's own value = input row r - 4 l + 1, columns
+                        // 2 lane + 3 l, +1 of its ring slot (an aligned 16-byte piece for even l)
+                        const d2 h = *reinterpret_cast<const d2 *>(winA + wrap(sl + NS - (4 * l - 1) % NS) * kSInW + 3 * l);
+                        v.x = in0 ? v.x : h.x;
+                        v.y = in1 ? v.y : h.y;
+                    } else {
+                        v.x = in0 ? v.x : 0.0;
+                        v.y = in1 ? v.y : 0.0;
+                    }
+                    *reinterpret_cast<d2 *>(B + (l - 1) * kBRow + 2 * lane) = v;
+                }
+            };
+            switch (R) {
+                case 0: run(std::integral_constant<int, 0>{}); break;
+                case 1: run(std::integral_constant<int, 1>{}); break;
+                case 2: run(std::integral_constant<int, 2>{}); break;
+                case 3: run(std::integral_constant<int, 3>{}); break;
+                case 4: run(std::integral_constant<int, 4>{}); break;
+                case 5: run(std::integral_constant<int, 5>{}); break;
+                default: run(std::integral_constant<int, 6>{}); break;
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
-        // intermediate row r (interior row i0 - 9 + r) is complete; level 2 picks up row r - 1 from B first, then this
-        // row takes its place (a wave's LDS operations execute in order)
-        d2 wb[4];
-        if constexpr (FULL) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) wb[q] = *reinterpret_cast<const d2 *>(winB + 2 * q);
-        }
+        // ---- level 1: input row r ----
         {
-            const int im = i0 - 9 + r;
-            const bool row_in = im >= 0 && im < a.m;
+            double win[8];
+            {
+                d2 w4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const d2 *>(winA + sl * kSInW + 2 * q);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    win[2 * q] = w4[q].x;
+                    win[2 * q + 1] = w4[q].y;
+                }
+            }
+            apply_row<EVAL, 7, P>(6, win, pa[0], pb[0], W, F);
             d2 v;
-            v.x = (row_in && c0_in) ? p1a[P] : 0.0;
-            v.y = (row_in && c1_in) ? p1b[P] : 0.0;
-            if constexpr (DIRI) {
-                // the cell's own input value: input row r - 3 (slot (P + 4) mod 7, still resident for D <= 4)
-                const double *cell = winA + ((P + 4) % 7) * kSInW + 3;
+            v.x = pa[0][P];
+            v.y = pb[0][P];
+            pa[0][P] = 0.0;
+            pb[0][P] = 0.0;
+            const int row = i0 - 3 * K - 3 + r;
+            const bool row_in = row >= 0 && row < a.m;
+            const bool in0 = row_in && cin0[1], in1 = row_in && cin1[1];
+            if (DIRI) {
+                // source value: input row r - 3, columns 2 lane + 3, +1 (8-byte aligned only)
+                const double *cell = winA + wrap(sl + NS - 3) * kSInW + 3;
                 const double h0 = cell[0], h1 = cell[1];
-                v.x = (row_in && c0_in) ? v.x : h0;
-                v.y = (row_in && c1_in) ? v.y : h1;
+                v.x = in0 ? v.x : h0;
+                v.y = in1 ? v.y : h1;
+            } else {
+                v.x = in0 ? v.x : 0.0;
+                v.y = in1 ? v.y : 0.0;
             }
             *reinterpret_cast<d2 *>(B + 2 * lane) = v;
-            p1a[P] = 0.0;
-            p1b[P] = 0.0;
         }
+        // The compiler does not know that the LDS-DMA below overwrites a ring slot: with D at its maximum that is the
+        // very slot the halo-cell reads above took their values from, so nothing of this step may sink below it.
+        asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
-        // ---- level 2: intermediate row r - 1 into the output rows; output row r - 1 (interior row i0 - 13 + r) is
-        //      then complete ----
-        if constexpr (FULL) {
-            double win[8];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                win[2 * q] = wb[q].x;
-                win[2 * q + 1] = wb[q].y;
-            }
-            apply_row<EVAL, 7, Q>(6, win, p2a, p2b, W, F);
-            const int ro = i0 - 13 + r;
-            const bool live = ro >= i0 && ro < row_hi;
-            const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
-                out_strip + (size_t) (max(ro, 0) + 4) * a.ld, 0, live ? row_bytes : 0u, 0x00020000);
-            d2 v;
-            v.x = p2a[Q];
-            v.y = p2b[Q];
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, store_off, 0, 0);
-            p2a[Q] = 0.0;
-            p2b[Q] = 0.0;
-        } else {
-            __builtin_amdgcn_raw_buffer_store_b128((u32x4){0u, 0u, 0u, 0u}, nowhere, 0, 0, 0);
-        }
-        issue(r + D, (P + D) % 7);
+        issue(r + D, wrap(sl + D));
         __builtin_amdgcn_sched_barrier(0);
     };
 
-    using T = std::true_type;
-    using Fa = std::false_type;
-#define LORA_STEP7(r0, FULLT)                                  \
-    step((r0) + 0, std::integral_constant<int, 0>{}, FULLT{}); \
-    step((r0) + 1, std::integral_constant<int, 1>{}, FULLT{}); \
-    step((r0) + 2, std::integral_constant<int, 2>{}, FULLT{}); \
-    step((r0) + 3, std::integral_constant<int, 3>{}, FULLT{}); \
-    step((r0) + 4, std::integral_constant<int, 4>{}, FULLT{}); \
-    step((r0) + 5, std::integral_constant<int, 5>{}, FULLT{}); \
-    step((r0) + 6, std::integral_constant<int, 6>{}, FULLT{});
-    LORA_STEP7(0, Fa)
+    int sl0 = 0;  // ring slot of the first step of the group (always 0 when NS == 7)
     for (int g = 0; g < a.groups; ++g) {
-        if (SYNC) __builtin_amdgcn_s_barrier();
-        const int r0 = 7 + 7 * g;
-        LORA_STEP7(r0, T)
+        if (SYNC == 1) __builtin_amdgcn_s_barrier();
+        const int r0 = 7 * g;
+        auto slot = [&](int k) { return NS == 7 ? k : (sl0 + k >= NS ? sl0 + k - NS : sl0 + k); };
+        step(r0 + 0, slot(0), std::integral_constant<int, 0>{});
+        step(r0 + 1, slot(1), std::integral_constant<int, 1>{});
+        step(r0 + 2, slot(2), std::integral_constant<int, 2>{});
+        step(r0 + 3, slot(3), std::integral_constant<int, 3>{});
+        step(r0 + 4, slot(4), std::integral_constant<int, 4>{});
+        step(r0 + 5, slot(5), std::integral_constant<int, 5>{});
+        step(r0 + 6, slot(6), std::integral_constant<int, 6>{});
+        if (NS != 7) sl0 = sl0 + 7 >= NS ? sl0 + 7 - NS : sl0 + 7;
     }
-#undef LORA_STEP7
     // drain: the last D loads target this wave's LDS, which the next workgroup on this CU may own
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EVAL, int D, int SYNC, bool DIRI>
+template <int EVAL, int K, int D, int SYNC, bool DIRI>
 hipError_t launch_stream_t(const Plan &p, const ArgsStream &a, hipStream_t s) {
     Taps49 w;
     for (int k = 0; k < 49; ++k) w.w[k] = p.w[k];
@@ -218,61 +277,80 @@ hipError_t launch_stream_t(const Plan &p, const ArgsStream &a, hipStream_t s) {
             f.v[t][e] = p.lowrank.v[t][e];
         }
     f.rc = p.lowrank_rc;
+    if (EVAL == EVAL_NEST)
+        for (int k = 0; k < 4; ++k) {
+            f.u[0][k] = p.nest_g[k];
+            f.v[0][k] = p.nest_a[k];
+        }
     const long waves = (long) a.strips * a.chunks;
     const long nblocks = (waves + 3) / 4;
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((stencil2d_stream2_kernel<EVAL, D, SYNC, DIRI>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w, f);
+    hipLaunchKernelGGL((stencil2d_stream_kernel<EVAL, K, D, SYNC, DIRI>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w, f);
     return hipGetLastError();
 }
 
-template <int EVAL>
-hipError_t launch_stream_e(const Plan &p, const ArgsStream &a, hipStream_t s) {
-    const bool sync = p.stream_sync != 0;
-    if (a.dirichlet)  // re-reads the input row three steps back: at most 4 rows in flight
-        return sync ? launch_stream_t<EVAL, 4, 1, true>(p, a, s) : launch_stream_t<EVAL, 4, 0, true>(p, a, s);
-#define LORA_STREAM_D(DD)     \
-    if (p.stream_depth == DD) \
-        return sync ? launch_stream_t<EVAL, DD, 1, false>(p, a, s) : launch_stream_t<EVAL, DD, 0, false>(p, a, s);
-    LORA_STREAM_D(2)
-    LORA_STREAM_D(3)
-    LORA_STREAM_D(5)
-    LORA_STREAM_D(6)
-#undef LORA_STREAM_D
-    return sync ? launch_stream_t<EVAL, 4, 1, false>(p, a, s) : launch_stream_t<EVAL, 4, 0, false>(p, a, s);
+template <int EVAL, int K>
+hipError_t launch_stream_e(const Plan &p, const ArgsStream &a, bool dirichlet, hipStream_t s) {
+    const int sync = p.stream_sync;
+#define LORA_STREAM_GO(DD, DIRI)                                         \
+    return sync == 2   ? launch_stream_t<EVAL, K, DD, 2, DIRI>(p, a, s)   \
+           : sync == 1 ? launch_stream_t<EVAL, K, DD, 1, DIRI>(p, a, s)   \
+                       : launch_stream_t<EVAL, K, DD, 0, DIRI>(p, a, s);
+    if constexpr (K == 2) {
+        if (dirichlet) {  // re-reads the input row three steps back: at most 4 rows in flight
+            LORA_STREAM_GO(4, true)
+        }
+        if (p.stream_depth == 2) { LORA_STREAM_GO(2, false) }
+        if (p.stream_depth == 3) { LORA_STREAM_GO(3, false) }
+        if (p.stream_depth == 6) { LORA_STREAM_GO(6, false) }
+        LORA_STREAM_GO(4, false)
+    } else {
+        if (p.stream_depth == 2) { LORA_STREAM_GO(2, false) }
+        LORA_STREAM_GO(3, false)
+    }
+#undef LORA_STREAM_GO
 }
 
 }  // namespace
 
-// Rows per chunk: as long as possible (the 12 + 6 recomputed rows are per chunk) while the launch still has a whole
-// number of "rounds" of the chip's resident waves -- 256 CUs x 16 waves -- so that no round runs half empty.
-int stream2_rows_per_chunk(const Plan &p, int rows_total, int strips) {
-    if (p.stream_rows > 0) {
-        int k = (p.stream_rows + 6 + 6) / 7;
-        return 7 * (k < 2 ? 2 : k) - 6;
-    }
+// Rows per chunk.  A chunk costs 7 K - 1 extra steps (recomputed rows), so chunks should be long; but the launch should
+// also fill every CU evenly: with j workgroups on most CUs and j + 1 on a few, the few set the pace (measured,
+// star2d1r 16384^2, K = 4: 435 rows = 5.9 workgroups per CU 939 GStencils/s, 582 rows = 4.5 per CU 884; box2d3r 8192^2:
+// 330 rows = 1.9 per CU 663, 295 rows = 2.2 per CU 535).  So: the fewest whole workgroups-per-CU j whose chunks are no
+// longer than a limit around which the rate is flat (a few rounds of workgroups also even out the speed of waves).
+int stream_rows_per_chunk(const Plan &p, int K, int rows_total, int strips) {
+    const int lag = 7 * K - 1;  // steps of a chunk beyond its output rows
+    auto fit = [&](long rows) {
+        long g = (rows + lag + 6) / 7;
+        if (g < K + 1) g = K + 1;
+        return (int) (7 * g - lag);
+    };
+    if (p.stream_rows > 0) return fit(p.stream_rows);
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess) {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    const long resident = 16L * cus;
-    int best = 0;
-    for (int round = 1; round <= 64; ++round) {
-        long chunks = resident * round / strips;
+    const int limit = K == 2 ? 640 : 448;
+    int best = fit(rows_total);
+    // at least 4 (K = 2: memory-bound, wants its full 16 waves per CU) or 2 (K = 4) workgroups per CU
+    for (int j = (K == 2 ? 4 : 2); j <= 256; ++j) {
+        const long chunks = 4L * cus * j / strips;  // 4 waves (strips) per workgroup
         if (chunks < 1) continue;
-        long rows = (rows_total + chunks - 1) / chunks;
-        long k = (rows + 6 + 6) / 7;
-        if (k < 2) k = 2;
-        rows = 7 * k - 6;
-        best = (int) rows;
-        if (rows <= 640) break;
+        best = fit((rows_total + chunks - 1) / chunks);
+        if (best <= limit) break;
     }
-    if (best <= 0) best = 8;
     return best;
 }
 
-hipError_t launch_2d_stream2(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
+int stream_strip_width(int K) { return stream_out_w(K); }
+
+// K = 2 or 4 applications in one launch over interior rows [begin, end)
+hipError_t launch_2d_stream(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s) {
     if (end <= begin) return hipSuccess;
+    if (K != 2 && K != 4) return hipErrorInvalidValue;
+    const bool dirichlet = p.boundary == LORA_BC_DIRICHLET;
+    if (K == 4 && dirichlet) return hipErrorNotSupported;  // the driver keeps K = 2 under the Dirichlet option
     ArgsStream a;
     a.in = in;
     a.out = out;
@@ -281,33 +359,37 @@ hipError_t launch_2d_stream2(const Plan &p, const double *in, double *out, int b
     a.ld = a.n + 8;
     a.row_begin = begin;
     a.row_end = end;
-    a.strips = (a.n + kSOutW - 1) / kSOutW;
-    a.rows = stream2_rows_per_chunk(p, end - begin, a.strips);
-    a.groups = (a.rows + 6) / 7;
+    a.strips = (a.n + stream_out_w(K) - 1) / stream_out_w(K);
+    a.rows = stream_rows_per_chunk(p, K, end - begin, a.strips);
+    a.groups = (a.rows + 7 * K - 1) / 7;
     a.chunks = (end - begin + a.rows - 1) / a.rows;
-    a.dirichlet = p.boundary == LORA_BC_DIRICHLET;
+#define LORA_STREAM_K(EV)                                                         \
+    return K == 2 ? launch_stream_e<EV, 2>(p, a, dirichlet, s) : launch_stream_e<EV, 4>(p, a, dirichlet, s);
     switch (p.fused_eval) {
+        case EVAL_NEST:
+            LORA_STREAM_K(EVAL_NEST)
         case EVAL_LR_DIAMOND:
-            return launch_stream_e<EVAL_LR_DIAMOND>(p, a, s);
+            LORA_STREAM_K(EVAL_LR_DIAMOND)
         case EVAL_LR_PYRAMID:
-            return launch_stream_e<EVAL_LR_PYRAMID>(p, a, s);
+            LORA_STREAM_K(EVAL_LR_PYRAMID)
         case EVAL_LR_PYRAMID_SYM:
-            return launch_stream_e<EVAL_LR_PYRAMID_SYM>(p, a, s);
+            LORA_STREAM_K(EVAL_LR_PYRAMID_SYM)
         case EVAL_LR_PYRAMID_SYM_GAP:
-            return launch_stream_e<EVAL_LR_PYRAMID_SYM_GAP>(p, a, s);
+            LORA_STREAM_K(EVAL_LR_PYRAMID_SYM_GAP)
         default:
             break;
     }
     switch (p.tapset) {
         case TAPS2D_DIAMOND:
-            return launch_stream_e<TAPS2D_DIAMOND>(p, a, s);
+            LORA_STREAM_K(TAPS2D_DIAMOND)
         case TAPS2D_STAR:
-            return launch_stream_e<TAPS2D_STAR>(p, a, s);
+            LORA_STREAM_K(TAPS2D_STAR)
         default:
-            return launch_stream_e<TAPS2D_BOX>(p, a, s);
+            LORA_STREAM_K(TAPS2D_BOX)
     }
+#undef LORA_STREAM_K
 }
 
-const char *kernel_name_2d_stream2(const Plan &) { return "stencil2d_stream2_kernel"; }
+const char *kernel_name_2d_stream(const Plan &) { return "stencil2d_stream_kernel"; }
 
 }  // namespace lora

@@ -18,7 +18,12 @@ namespace lora {
 // EVAL_LR_PYRAMID_SYM_GAP: additionally the middle term vanishes next to its centre (u_1[2] = u_1[4] = v_1[2] = 0), as in
 // the reference's own table, whose second factor is (0, 1, 0, -1, 0, 1, 0) (2d/main.cu:151-167 through 2d/gpu.cu:280-350):
 // those taps are skipped at compile time, 48 operations per input row.
-enum { EVAL_LR_DIAMOND = 3, EVAL_LR_PYRAMID = 4, EVAL_LR_PYRAMID_SYM = 5, EVAL_LR_PYRAMID_SYM_GAP = 6 };
+// EVAL_NEST: tables whose rows are multiples of NESTED mirror-symmetric profiles -- row dy is g[k] T_k with
+// k = 3 - |dy - 3| and T_0 = x3, T_k = a_k T_(k-1) + (x_(3-k) + x_(3+k)).  The reference's star2d1r table is one
+// (2d/main.cu:187-195: rows (1), 2 (1 2 1), 2 (1 2 4 2 1), (1 4 8 16 8 4 1): a = (2, 2, 4), g = (1, 2, 2, 1)), which
+// makes a row cost 6 operations for the three profiles plus 7 scattered multiply-adds: 13 per column instead of the 17
+// of the rank-1 + correction form (25 direct).  u[0][0..3] = g, v[0][1..3] = a.
+enum { EVAL_LR_DIAMOND = 3, EVAL_LR_PYRAMID = 4, EVAL_LR_PYRAMID_SYM = 5, EVAL_LR_PYRAMID_SYM_GAP = 6, EVAL_NEST = 7 };
 
 struct LowRankTaps {
     double u[3][7];  // vertical profiles
@@ -44,6 +49,24 @@ __device__ __forceinline__ void apply_row(const int j, const double (&win)[8], d
                         acc1[(r + ROT) % R] = fma(wt, win[dx + 1], acc1[(r + ROT) % R]);
                     }
                 }
+            }
+        }
+    } else if constexpr (EVAL == EVAL_NEST) {
+        double t0[4], t1[4];  // the four profiles of this row for column 0 / column 1
+        t0[0] = win[3];
+        t1[0] = win[4];
+#pragma unroll
+        for (int k = 1; k <= 3; ++k) {
+            t0[k] = fma(F.v[0][k], t0[k - 1], win[3 - k] + win[3 + k]);
+            t1[k] = fma(F.v[0][k], t1[k - 1], win[4 - k] + win[4 + k]);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int dy = j - r;
+            if (dy >= 0 && dy < 7) {
+                const int k = dy <= 3 ? dy : 6 - dy;
+                acc0[(r + ROT) % R] = fma(F.u[0][k], t0[k], acc0[(r + ROT) % R]);
+                acc1[(r + ROT) % R] = fma(F.u[0][k], t1[k], acc1[(r + ROT) % R]);
             }
         }
     } else if constexpr (EVAL == EVAL_LR_PYRAMID_SYM || EVAL == EVAL_LR_PYRAMID_SYM_GAP) {

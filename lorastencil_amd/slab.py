@@ -168,6 +168,9 @@ class HipStepper:
     def stepk_region(self, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
         self.plan.stepk_region(src.data_ptr(), dst.data_ptr(), begin, end, stream=self.stream)
 
+    def step2_region(self, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
+        self.plan.step2_region(src.data_ptr(), dst.data_ptr(), begin, end, stream=self.stream)
+
     def wrap(self, buf: torch.Tensor) -> None:
         """Periodic halo of the LOCAL array (lora_plan_halo, wrap mode): right along the unsplit dimensions; along
         the split one it only touches pad rows beyond the ghost zones, which nothing reads."""
@@ -221,8 +224,11 @@ class SlabDriver:
         thinnest = min(slab_layout(sid, global_dims, self.world_size, r).own for r in range(self.world_size))
         auto_every = exchange_every is None
         layout = None
-        default_apps = 8 if nd == 1 else 2  # applications of a fused launch (lora_plan_stepk)
-        for apps in ([default_apps, 1] if fused else [1]):
+        # applications of a fused launch (lora_plan_stepk): 8 in 1D, 4 (row-streaming kernel) or 2 in 2D, 2 in 3D -- the
+        # first candidate the stepper agrees with decides the ghost depth
+        default_apps = 8 if nd == 1 else 2
+        candidates = {1: [8], 2: [4, 2], 3: [2]}[nd]
+        for apps in (candidates + [1] if fused else [1]):
             need = radius * apps
             split = self.world_size > 1 or self._ring
             if auto_every:
@@ -413,14 +419,19 @@ class SlabDriver:
         self.valid = self.layout.ghost
 
     # ---- one launch (1 or 2 applications) ---------------------------------------------------------------
-    def _launch(self, fused: bool) -> None:
+    def _launch(self, napps: int) -> None:
+        """One launch of `napps` applications: the driver's own fused count (stepk_region), 2 (step2_region: the tail of
+        a run whose launches fuse four) or 1 (step_region)."""
         lay = self.layout
-        apps = self.apps if fused else 1
+        fused = napps > 1
+        apps = napps
         need = self.radius * apps
         src_i, dst_i = self.cur, 1 - self.cur
         src, dst = self.buf[src_i], self.buf[dst_i]
-        if fused:
+        if fused and napps == self.apps:
             sweep = getattr(self.stepper, "stepk_region", None) or self.stepper.step2_region
+        elif fused:
+            sweep = self.stepper.step2_region
         else:
             sweep = self.stepper.step_region
         if self.periodic:
@@ -492,16 +503,21 @@ class SlabDriver:
     def step(self) -> None:
         """One kernel application."""
         with self._on_stream():
-            self._launch(False)
+            self._launch(1)
 
     def run(self, times: int) -> None:
         """`times` kernel applications (fused pairs where the shape allows, starting at even time levels)."""
         t = 0
         with self._on_stream():
             while t < times:
-                if self.fused and self.steps_done % 2 == 0 and times - t >= self.apps:
-                    self._launch(True)
+                even = self.steps_done % 2 == 0
+                if self.fused and even and times - t >= self.apps:
+                    self._launch(self.apps)
                     t += self.apps
+                elif (self.fused and even and self.ndim == 2 and self.apps == 4 and times - t >= 2
+                      and hasattr(self.stepper, "step2_region")):
+                    self._launch(2)
+                    t += 2
                 else:
-                    self._launch(False)
+                    self._launch(1)
                     t += 1

@@ -239,7 +239,7 @@ def test_kernel_signature_names_every_selecting_option(L):
     p.set_option("lowrank_valu", 0)
     assert p.kernel_signature != s0  # another instantiation: measured traffic filed under s0 no longer applies
     p.set_option("stream", 1)
-    assert p.kernel_name == "stencil2d_stream2_kernel" and "depth=" in p.kernel_signature and "rows=" in p.kernel_signature
+    assert p.kernel_name == "stencil2d_stream_kernel" and "depth=" in p.kernel_signature and "rows=" in p.kernel_signature
     assert L.Plan("1d1r", (4096,)).kernel_signature == "stencil1d_fusedk_kernel[k=8]"
     with pytest.raises(L.LoraError):
-        L.Plan("1d1r", (2**31 - 9,))  # padded extent would overflow the kernels' 32-bit indices
+        L.Plan("1d1r", (2**31 - 8,))  # padded extent n + 8 would overflow the kernels' 32-bit indices

@@ -204,16 +204,23 @@ def test_mfma_variant_real_weights_and_scaling(L, O):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# temporal fusion: two applications per launch (kernels_2d_fused.hip) must equal two launches
+# temporal fusion: K applications per launch must equal K launches.  Three 2D kernels: the row-streaming kernel with
+# four applications per launch (kernels_2d_stream.hip; the default), the same with two, and the tile kernel
+# (kernels_2d_fused.hip, two)
 # ---------------------------------------------------------------------------------------------------------
+FUSED_2D = {"stream4": {}, "stream2": {"steps_per_launch": 2}, "tile2": {"stream": 0, "steps_per_launch": 2}}
+
+
+@pytest.mark.parametrize("kernel", list(FUSED_2D))
 @pytest.mark.parametrize("shape,dims", [("star2d1r", (64, 128)), ("star2d1r", (26, 122)), ("star2d1r", (52, 244)),
                                         ("star2d1r", (53, 246)), ("star2d1r", (40, 130)), ("star2d1r", (1, 2)),
                                         ("star2d1r", (300, 700)), ("box2d3r", (64, 128)), ("box2d3r", (90, 250)),
-                                        ("star2d3r", (64, 128)), ("star2d3r", (27, 124))])
-def test_fused_two_step_launches_equal_step_by_step(L, O, shape, dims):
+                                        ("star2d3r", (64, 128)), ("star2d3r", (27, 124)), ("star2d1r", (37, 104)),
+                                        ("star2d1r", (700, 118)), ("box2d3r", (13, 232)), ("star2d3r", (40, 2100))])
+def test_fused_two_step_launches_equal_step_by_step(L, O, shape, dims, kernel):
     a = O.reference_input(shape, dims)
-    for t in (4, 5, 6, 7):
-        got = plan_run(L, shape, a, t, options={"steps_per_launch": 2})
+    for t in (4, 5, 6, 7, 8, 9, 10, 11):
+        got = plan_run(L, shape, a, t, options=FUSED_2D[kernel])
         exp = O.run(shape, a, t)
         # whole padded buffer: interior AND the halo state the step-by-step driver leaves behind
         if np.abs(exp).max() < 2.0 ** 53:
@@ -228,7 +235,7 @@ def test_fused_persistent_workgroups(L, O, shape, dims):
     """persistent = 1: 2 workgroups per CU walk the tiles and prefetch the next window into registers."""
     a = O.reference_input(shape, dims)
     for t in (4, 5):
-        got = plan_run(L, shape, a, t, options={"steps_per_launch": 2, "persistent": 1})
+        got = plan_run(L, shape, a, t, options={"stream": 0, "steps_per_launch": 2, "persistent": 1})
         assert np.array_equal(got, O.run(shape, a, t)), f"{shape} {dims} t={t}"
 
 
@@ -236,7 +243,7 @@ def test_fused_persistent_workgroups(L, O, shape, dims):
 def test_fused_tile_heights(L, O, rows):
     for shape, dims in (("star2d1r", (150, 380)), ("box2d3r", (70, 130))):
         a = O.reference_input(shape, dims)
-        got = plan_run(L, shape, a, 4, options={"steps_per_launch": 2, "fused_rows": rows})
+        got = plan_run(L, shape, a, 4, options={"stream": 0, "steps_per_launch": 2, "fused_rows": rows})
         assert np.array_equal(got, O.run(shape, a, 4)), (shape, rows)
 
 
@@ -251,10 +258,11 @@ def test_fused_lowrank_evaluation_on_the_vector_pipe(L, O):
         exp = O.run(shape, a, 4)
         plan = L.Plan(shape, dims)
         assert plan.get_option("fused_eval") == expect_eval, shape
-        assert np.array_equal(plan_run(L, shape, a, 4), exp), shape
-        assert np.array_equal(plan_run(L, shape, a, 4, options={"lowrank_valu": 0}), exp), shape
-        assert np.array_equal(plan_run(L, shape, a, 4, options={"lowrank_valu": 2}), exp), shape  # plain pyramid form
-        assert np.array_equal(plan_run(L, shape, a, 4, options={"lowrank_valu": 3}), exp), shape  # symmetric, no gap
+        for k in FUSED_2D.values():
+            assert np.array_equal(plan_run(L, shape, a, 4, options=k), exp), shape
+            assert np.array_equal(plan_run(L, shape, a, 4, options={**k, "lowrank_valu": 0}), exp), shape
+            assert np.array_equal(plan_run(L, shape, a, 4, options={**k, "lowrank_valu": 2}), exp), shape  # plain pyramid form
+            assert np.array_equal(plan_run(L, shape, a, 4, options={**k, "lowrank_valu": 3}), exp), shape  # symmetric, no gap
         off = L.Plan(shape, dims).set_option("lowrank_valu", 0)
         assert off.get_option("fused_eval") == {"star2d1r": 0, "box2d3r": 2, "box2d1r": 2, "star2d3r": 1}[shape]
     # scaled star2d1r taps keep the form; real-valued data within rounding of the oracle
@@ -279,8 +287,41 @@ def test_fused_step2_direct_call_and_regions(L, O):
     shape, dims = "star2d1r", (200, 380)
     a = O.reference_input(shape, dims)
     exp = O.run(shape, a, 2)  # buffer 0 after two sweeps: interior + the input halo
+    assert L.Plan(shape, dims).kernel_name == "stencil2d_stream_kernel"
+    assert L.Plan(shape, dims).get_option("steps_per_launch") == 4
+    assert L.Plan(shape, dims).set_boundary("dirichlet").get_option("steps_per_launch") == 2  # four: reference BC only
+    assert L.Plan(shape, dims).set_option("stream", 0).get_option("steps_per_launch") == 2
+    _check_step2_and_regions(L, O, shape, dims, a, exp, {"stream": 0}, "stencil2d_fused2_kernel")
+    _check_step2_and_regions(L, O, shape, dims, a, exp, {}, "stencil2d_stream_kernel")
+    # four applications in one call: lora_plan_stepk, whole grid and regions in any order
+    exp4 = O.run(shape, a, 4)
     plan = L.Plan(shape, dims)
-    assert plan.set_option("steps_per_launch", 2).kernel_name == "stencil2d_fused2_kernel"
+    src = torch.from_numpy(a).cuda()
+    dst = torch.from_numpy(a).cuda()
+    dst[4:-4, 4:-4] = -1.0
+    plan.stepk(src, dst)
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), exp4)
+    dst[4:-4, 4:-4] = -1.0
+    for b, e in ((100, 200), (0, 26), (26, 100)):
+        plan.stepk_region(src, dst, b, e)
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), exp4)
+    with pytest.raises(L.LoraError):
+        L.Plan("star2d1r", (64, 64)).set_option("steps_per_launch", 8)  # 2D fuses two or four applications
+    with pytest.raises(L.LoraError):
+        L.Plan("star3d1r", (8, 8, 64)).set_option("steps_per_launch", 4)  # 3D kernels fuse two
+    with pytest.raises(L.LoraError):
+        L.Plan("1d1r", (64,)).set_option("steps_per_launch", 3)
+
+
+def _check_step2_and_regions(L, O, shape, dims, a, exp, opts, name):
+    import torch
+
+    plan = L.Plan(shape, dims)
+    for k, v in opts.items():
+        plan.set_option(k, v)
+    assert plan.set_option("steps_per_launch", 2).kernel_name == name
     src = torch.from_numpy(a).cuda()
     dst = torch.from_numpy(a).cuda()  # same halo as the source, interior to be overwritten
     dst[4:-4, 4:-4] = -1.0
@@ -292,10 +333,6 @@ def test_fused_step2_direct_call_and_regions(L, O):
         plan.step2_region(src, dst, b, e)
     torch.cuda.synchronize()
     assert np.array_equal(dst.cpu().numpy(), exp)
-    with pytest.raises(L.LoraError):
-        L.Plan("star2d1r", (64, 64)).set_option("steps_per_launch", 4)  # 2D / 3D fuse two applications
-    with pytest.raises(L.LoraError):
-        L.Plan("1d1r", (64,)).set_option("steps_per_launch", 3)
 
 
 @pytest.mark.parametrize("shape", ["1d1r", "1d2r"])
@@ -404,8 +441,26 @@ def test_fused_long_run_real_weights(L, O):
     a = rng.standard_normal(O.padded_shape(shape, dims))
     w = O.effective_weights(shape) / 100.0
     for t in (20, 21, 22, 23):
-        got = plan_run(L, shape, a, t, weights=w, options={"steps_per_launch": 2})
-        assert rel_err(got, O.run(shape, a, t, weights=w)) < 1e-13
+        for k in FUSED_2D.values():
+            got = plan_run(L, shape, a, t, weights=w, options=k)
+            assert rel_err(got, O.run(shape, a, t, weights=w)) < 1e-13
+
+
+@pytest.mark.parametrize("opts", [{"stream_rows": 8}, {"stream_rows": 50, "stream_depth": 2, "stream_sync": 0},
+                                  {"stream_sync": 2}, {"stream_depth": 3, "stream_rows": 200},
+                                  {"steps_per_launch": 2, "stream_depth": 6, "stream_rows": 29},
+                                  {"steps_per_launch": 2, "stream_depth": 2, "stream_sync": 2}])
+def test_row_streaming_kernel_options_do_not_change_results(L, O, opts):
+    """Chunk height, rows in flight and the strip-synchronising barriers of kernels_2d_stream.hip only move work
+    around: random real data, bit-for-bit the same grid as the default configuration (and the oracle to rounding)."""
+    rng = np.random.default_rng(11)
+    for shape, dims in (("star2d1r", (301, 1000)), ("box2d3r", (100, 250)), ("star2d3r", (64, 2100))):
+        w = O.effective_weights(shape)
+        w = w / w.sum()
+        a = rng.standard_normal(O.padded_shape(shape, dims))
+        base = plan_run(L, shape, a, 9, weights=w, options={"steps_per_launch": opts.get("steps_per_launch", 4)})
+        assert np.array_equal(plan_run(L, shape, a, 9, weights=w, options=opts), base), (shape, opts)
+        assert rel_err(base, O.run(shape, a, 9, weights=w)) < 1e-13
 
 
 @pytest.mark.parametrize("zc", [1, 2, 4, 7, 16, 40])
@@ -877,9 +932,10 @@ def test_full_size_constant_field_and_windows(L, O, shape, dims):
     plan.step(src, dst2)
     torch.cuda.synchronize()
     assert bool((dst2 == 2.0 * dst).all())
-    # (4) the default two-applications-per-launch kernel == two single sweeps through a zero-halo buffer, everywhere
+    # (4) the fused kernels == single sweeps through buffers whose halo alternates between 0 and the input's, everywhere
     #     (small integers: exact whatever the summation order of the low-rank evaluation)
-    assert plan.get_option("steps_per_launch") == 2
+    k_apps = plan.get_option("steps_per_launch")
+    assert k_apps == (4 if len(dims) == 2 else 2)
     del dst
     two = src.clone()                 # buffer 0 again after two sweeps: the input's halo, new interior
     plan.step(dst2, two)              # dst2 = sweep(src) with a zero halo
@@ -887,6 +943,16 @@ def test_full_size_constant_field_and_windows(L, O, shape, dims):
     plan.step2(src, fused)
     torch.cuda.synchronize()
     assert torch.equal(fused, two)
+    if k_apps == 4:                   # the default 2D launch: four applications
+        three = torch.zeros_like(src)
+        plan.step(two, three)
+        four = src.clone()
+        plan.step(three, four)
+        del three
+        fused.copy_(src)
+        plan.stepk(src, fused)
+        torch.cuda.synchronize()
+        assert torch.equal(fused, four)
 
 
 @pytest.mark.parametrize("shape,dims,dtype", [
@@ -1113,8 +1179,8 @@ def test_three_rank_slabs_on_one_gpu_equal_single_rank(L, O, shape, dims, times,
             assert np.array_equal(got, exp)
         else:
             assert rel_err(got, exp) < 1e-13
-    assert fused  # 2D and 3D, fp64 and bf16: two applications per launch
-    assert ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * (8 if len(dims) == 1 else 2) * every
+    assert fused  # 1D: eight applications per launch, 2D: four (row-streaming kernel), 3D fp64 and bf16: two
+    assert ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * {1: 8, 2: 4, 3: 2}[len(dims)] * every
 
 
 @pytest.mark.parametrize("boundary", ["dirichlet", "periodic"])
@@ -1182,6 +1248,26 @@ for shape, dims, steps in (("star2d1r", (256, 384), 7), ("star3d1r", (24, 20, 64
         if not same:
             print("RING_MISMATCH", shape, mode)
         ok = ok and same
+# the deferred wait over a STREAM-ORDERED backend: non-periodic, fused (four applications per launch), ghost zones
+# refreshed every 2 launches, so a launch sweeps its deep interior, waits for the ghost rows in flight, then sweeps its
+# rims.  (A ring of one under the reference boundary is a rehearsal of one rank's share, not a physical result: what
+# must hold is that the overlapped / deferred schedule equals the plain one bit for bit.)  The driver is built while a
+# side stream is current and run from the default stream: everything it enqueues must follow its own stream.
+a = O.reference_input("star2d1r", (512, 384))
+res = []
+for defer, overlap in (("1", True), ("0", False)):
+    os.environ["LORA_SLAB_DEFER_WAIT"] = defer
+    os.environ["LORA_SLAB_EXCHANGE"] = "p2p"
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        drv = slab.SlabDriver("star2d1r", (512, 384), device="cuda:0", ring_of_one=True, exchange_every=2, overlap=overlap)
+    assert drv.fused and drv.apps == 4 and drv.layout.ghost == 24 and drv.defer_wait == (defer == "1")
+    drv.load_global(a); drv.refresh_ghosts(); drv.run(23)
+    side.synchronize(); torch.cuda.synchronize()
+    res.append(drv.result().cpu().numpy().copy())
+if not np.array_equal(res[0], res[1]):
+    print("DEFER_MISMATCH")
+    ok = False
 dist.destroy_process_group()
 print("RCCL_OK" if ok else "RCCL_MISMATCH")
 '''

@@ -20,7 +20,7 @@ if ROOT not in sys.path:
 class OracleStepper:
     """CPU stand-in for HipStepper (tests only)."""
 
-    def __init__(self, layout, weights, wants_fused=True, dirichlet=False):
+    def __init__(self, layout, weights, wants_fused=True, dirichlet=False, apps=None):
         from lorastencil_amd import ops
 
         self.dirichlet = dirichlet
@@ -28,22 +28,28 @@ class OracleStepper:
         self.w = weights
         self.h = ops.halo(layout.shape)
         self.wants_fused = wants_fused
-        self.apps_per_launch = 8 if len(self.h) == 1 else 2
-        self.calls = {"step": 0, "step2": 0}
+        self.apps_per_launch = apps or (8 if len(self.h) == 1 else 2)
+        self.calls = {"step": 0, "step2": 0, "two": 0}
 
-    def stepk_region(self, src, dst, begin, end):
+    def step2_region(self, src, dst, begin, end):
+        """Two applications (lora_plan_step2_region): the tail launches of a driver that fuses four."""
+        self.calls["two"] += 1
+        self.stepk_region(src, dst, begin, end, apps=2)
+
+    def stepk_region(self, src, dst, begin, end, apps=None):
         """apps_per_launch applications in one call (lora_plan_stepk_region): cells outside the local interior are 0 at
         odd intermediate levels and the source's halo value at even ones."""
         from oracle import oracle as O
 
+        apps = apps or self.apps_per_launch
         self.calls["step2"] += 1
         if end <= begin:
             return
         s = np.ascontiguousarray(src.numpy())
         cur = s
-        for level in range(1, self.apps_per_launch + 1):
+        for level in range(1, apps + 1):
             cur = O.step(self.shape, cur, self.w)  # zeros outside the local interior
-            if (level % 2 == 0 or self.dirichlet) and level < self.apps_per_launch:
+            if (level % 2 == 0 or self.dirichlet) and level < apps:
                 for d, k in enumerate(self.h):
                     for side in (slice(0, k), slice(-k, None)):
                         idx = (slice(None),) * d + (side,)
@@ -157,7 +163,8 @@ def test_bf16_slabs_equal_single_rank(engine_built):
     assert np.array_equal(got, O.run_bf16(shape, bits, times))
 
 
-def _worker(rank, world, port, shape, dims, times, overlap, q, fused=None, exchange_every=None, boundary="reference"):
+def _worker(rank, world, port, shape, dims, times, overlap, q, fused=None, exchange_every=None, boundary="reference",
+            apps=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -170,7 +177,7 @@ def _worker(rank, world, port, shape, dims, times, overlap, q, fused=None, excha
         drv = slab.SlabDriver(shape, dims, device="cpu", overlap=overlap, boundary_rows=4, fused=fused,
                               exchange_every=exchange_every, boundary=boundary,
                               stepper_factory=lambda lay: OracleStepper(lay, w, wants_fused=fused is not False,
-                                                                        dirichlet=boundary == "dirichlet"))
+                                                                        dirichlet=boundary == "dirichlet", apps=apps))
         drv.load_global(a)
         # split the run in two calls: the driver must be resumable at any time level
         drv.run(times // 2)
@@ -189,12 +196,12 @@ def _free_port():
 
 
 def run_slabs(world, shape, dims, times, overlap=True, fused=None, exchange_every=None, info=False,
-              boundary="reference"):
+              boundary="reference", apps=None):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, world, port, shape, dims, times, overlap, q, fused, exchange_every,
-                                               boundary))
+                                               boundary, apps))
              for r in range(world)]
     for p in procs:
         p.start()
@@ -253,6 +260,23 @@ def test_ghost_zone_schedules_equal_single_rank(engine_built, world, shape, dims
     assert was_fused == (fused is None)
     if was_fused and times // 2 >= apps:  # the run is split in two calls of times // 2 and the rest
         assert calls["step2"] > 0
+
+
+@pytest.mark.parametrize("world,shape,dims,times,every", [
+    (2, "star2d1r", (128, 64), 11, 1),    # four applications per launch (row-streaming kernel): 12-row ghost zones;
+    (2, "star2d1r", (192, 64), 23, 2),    # the run is split 11 + 12: 4 + 4 + 2 + 1 and 4 + 4 + 4
+    (3, "star2d3r", (192, 32), 14, 1),
+])
+def test_four_application_launches_across_slabs(engine_built, world, shape, dims, times, every):
+    from oracle import oracle as O
+
+    a = O.reference_input(shape, dims)
+    expect = O.run(shape, a, times)  # 23 steps of the integer taps leave the exact range: compared to rounding below
+    got, was_fused, e, ghost, calls = run_slabs(world, shape, dims, times, exchange_every=every, info=True, apps=4)
+    assert was_fused and e == every and ghost == 3 * 4 * every
+    assert calls["step2"] > 0 and (times != 23 or calls["two"] > 0)
+    scale = np.abs(expect).max()
+    assert np.abs(got - expect).max() <= 1e-12 * scale
 
 
 @pytest.mark.parametrize("world,shape,dims,times,fused", [

@@ -80,6 +80,47 @@ def parity():
                     if not np.array_equal(got, exp):
                         bad += 1
                         print("FAIL region", shape, dims, opts, flush=True)
+    # K = 4: one launch = four sweeps of the reference driver from an even level (O.run keeps the alternating halo)
+    for shape in ("star2d1r", "box2d3r", "star2d3r"):
+        for dims in ((64, 128), (100, 250), (37, 104), (301, 1000), (8, 2), (1, 104), (13, 208), (700, 110), (40, 2100)):
+            for opts in ({}, {"stream_rows": 8}, {"stream_rows": 50, "stream_depth": 2, "stream_sync": 0},
+                         {"stream_sync": 2}, {"lowrank_valu": 0}):
+                w = L.effective_weights(shape)
+                w = w / w.sum()
+                ps = L.padded_shape(shape, dims)
+                a = rng.standard_normal(ps)
+                plan = L.Plan(shape, dims).set_weights(w)
+                plan.set_option("stream", 1).set_option("steps_per_launch", 4)
+                for k, v in opts.items():
+                    plan.set_option(k, v)
+                assert plan.get_option("steps_per_launch") == 4
+                src = torch.from_numpy(a).cuda()
+                dst = torch.from_numpy(a).cuda()
+                dst[4:-4, 4:-4] = -7.0
+                plan.stepk(src, dst)
+                torch.cuda.synchronize()
+                got = dst.cpu().numpy()
+                ref = O.run(shape, a, 4, weights=w)
+                err = np.abs(got - ref).max()
+                ok = err < 1e-12 and np.array_equal(got[:4], a[:4]) and np.array_equal(got[:, :4], a[:, :4])
+                bad += not ok
+                print(("ok  " if ok else "FAIL"), "K=4", shape, dims, opts, f"err {err:.2e}", flush=True)
+            # the time-step driver with the mixed 4 / 2 / 1 schedule, halo included
+            a = O.reference_input(shape, dims)
+            w = L.effective_weights(shape)
+            w = w / w.sum()
+            for times in (4, 5, 6, 7, 8, 9, 10, 11, 13):
+                plan = L.Plan(shape, dims).set_weights(w)
+                plan.set_option("stream", 1).set_option("steps_per_launch", 4)
+                b0 = torch.from_numpy(a).cuda()
+                b1 = torch.zeros_like(b0)
+                plan.run(b0, b1, times)
+                torch.cuda.synchronize()
+                got = (b0, b1)[times % 2].cpu().numpy()
+                ref = O.run(shape, a, times, weights=w)
+                ok = np.abs(got - ref).max() < 1e-11 and np.array_equal(got[:4], ref[:4]) and np.array_equal(got[:, -4:], ref[:, -4:])
+                bad += not ok
+                print(("ok  " if ok else "FAIL"), "run K=4", shape, dims, times, flush=True)
     # Dirichlet: plan.run with the boundary option, stream vs tile
     for shape in ("star2d1r", "box2d3r"):
         for dims in ((64, 128), (100, 250), (301, 1000)):
@@ -124,18 +165,18 @@ def timing(out_path, quick):
         src = torch.randint(0, 100, ps, device=dev).to(torch.float64)
         dst = torch.zeros_like(src)
         pts = dims[0] * dims[1]
-        grid = [{"stream": 0}]
-        rows = [0, 127, 253, 379] if not quick else [0]
-        depth = [2, 3, 4, 5, 6] if not quick else [4]
-        for r, d, sy in itertools.product(rows, depth, [1, 0]):
-            grid.append({"stream": 1, "stream_rows": r, "stream_depth": d, "stream_sync": sy})
+        grid = [{"stream": 0, "steps_per_launch": 2}, {"steps_per_launch": 1}, {"steps_per_launch": 2}]
+        for lr in ([-1, 4] if shape == "star2d1r" else [-1]):
+            for r in ([0, 290, 330, 580, 870] if not quick else [0]):
+                grid.append({"steps_per_launch": 4, "stream_rows": r, "lowrank_valu": lr})
         for opts in grid:
             plan = L.Plan(shape, dims).set_weights(w)
             for k, v in opts.items():
                 plan.set_option(k, v)
-            t = time_fn(lambda: (plan.step2(src, dst), plan.step2(dst, src)), 10) / 2
-            record(kind="step2", shape=shape, dims=dims, opts=opts, kernel=plan.kernel_name, us=round(t * 1e6, 1),
-                   gstencils=round(2 * pts / t / 1e9, 1), real_tbs=round(2 * pts * 8 / t / 1e12, 3))
+            apps = plan.get_option("steps_per_launch")
+            t = time_fn(lambda: (plan.stepk(src, dst), plan.stepk(dst, src)), 10) / 2
+            record(kind="stepk", shape=shape, dims=dims, opts=opts, kernel=plan.kernel_signature, us=round(t * 1e6, 1),
+                   gstencils=round(apps * pts / t / 1e9, 1), real_tbs=round(2 * pts * 8 / t / 1e12, 3))
 
 
 def main():
