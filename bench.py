@@ -16,10 +16,12 @@ scaling, as BASELINE.json quotes the metric) with one RCCL halo exchange per ste
 torch.distributed.run child, before this process touches the GPU) and relays rank 0's line.
 
 The single JSON line also carries
-  roofline      for the dominant kernel: COMPULSORY bytes per launch (one read + one write of every interior point,
-                2 x sizeof(T) x points, however many applications the launch fuses) / its average launch duration
-                (HIP events on the launch stream around the fused launches of the timed region,
-                lora_plan_run_profiled), against the 8 TB/s HBM3E peak: `frac` <= 1 by construction.
+  roofline      for the dominant kernel, against both roofs (`hbm`, `fp64`; `bound` / `frac` name the nearer one).  hbm:
+                COMPULSORY bytes per launch (one read + one write of every interior point, 2 x sizeof(T) x points,
+                however many applications the launch fuses) / its average launch duration (HIP events on the launch
+                stream around the fused launches of the timed region, lora_plan_run_profiled), against the 8 TB/s
+                HBM3E peak: <= 1 by construction.  fp64: algorithmic flops (direct form) x applications per
+                launch / the same duration, against the 78.6 TFLOP/s fp64 FMA peak (matrix = vector rate on gfx950).
                 `frac_one_sweep_equiv` is SURVEY 8d's figure (16 B per point per APPLICATION: > 1 means the fused
                 launch beats what any one-sweep-per-launch kernel could reach); `copy_bw_frac` relates `achieved` to
                 a torch copy_ of the same grid timed in this run; `traffic` = measured HBM bytes per launch (rocprofv3
@@ -41,6 +43,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec; ~6.3 TB/s achievable copy)
+FP64_PEAK_TFLOPS = 78.6  # fp64 FMA peak: on gfx950 the matrix (MFMA) rate equals the vector rate (256 CUs x 4 SIMDs x 16
+#                          lanes x 2 flop x 2.4 GHz; DESIGN.md section 4 measures 64 cycles per v_mfma_f64_16x16x4)
+# algorithmic flops per point per application, direct form 2 nnz - 1
+FLOPS_PER_POINT = {"1d1r": 13, "1d2r": 17, "star2d1r": 49, "box2d3r": 97, "box2d1r": 97, "star2d3r": 25, "star3d1r": 13,
+                   "box3d1r": 53}
 OVERFLOW_STEPS = {"star2d1r": 140, "box2d3r": 120, "box2d1r": 120, "star2d3r": 200, "star3d1r": 300, "box3d1r": 180,
                   "1d1r": 240, "1d2r": 200}
 
@@ -352,6 +359,12 @@ def main():
     bytes_per_launch = local_points * 2.0 * esize          # compulsory: one read + one write of the grid
     achieved = bytes_per_launch / launch_s / 1e9
     one_sweep_equiv = achieved * apps                       # 2 x sizeof(T) per point per APPLICATION
+    # the other roof: algorithmic flops (direct form) against the fp64 FMA peak.  A launch that fuses K applications does
+    # K x the arithmetic on the same bytes, so deep fusion moves the kernel from the HBM roof towards this one; the
+    # line reports both and names the one the kernel sits closer to as `bound`.
+    flops_per_launch = float(FLOPS_PER_POINT.get(shape, 0)) * local_points * apps
+    tflops = flops_per_launch / launch_s / 1e12
+    hbm_frac, flop_frac = achieved / HBM_PEAK_GBS, (tflops / FP64_PEAK_TFLOPS if not bf16 else 0.0)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     tkey = f"{shape}:{'x'.join(map(str, dims))}:{world}:{signature}"
@@ -387,12 +400,16 @@ def main():
             },
             "value_reference_convention": round(value * L.ops.gstencil_factor(shape), 3),
             "roofline": {
-                "bound": "hbm",
+                "bound": "hbm" if hbm_frac >= flop_frac else "mfma",
                 "kernel": signature,
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "achieved": round(achieved, 1) if hbm_frac >= flop_frac else round(tflops, 2),
+                "peak": HBM_PEAK_GBS if hbm_frac >= flop_frac else FP64_PEAK_TFLOPS,
+                "unit": "GB/s" if hbm_frac >= flop_frac else "TFLOP/s",
+                "frac": round(max(hbm_frac, flop_frac), 4),
+                "hbm": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)},
+                "fp64": {"achieved": round(tflops, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(flop_frac, 4), "flops_per_point_algorithmic": FLOPS_PER_POINT.get(shape),
+                         "note": "fp64 matrix peak = vector peak on gfx950; the kernel issues v_fma_f64"},
                 "traffic": traffic,
                 # the same launch duration applied to the MEASURED bytes
                 "traffic_gbs": round(traffic / launch_s / 1e9, 1) if traffic else None,
@@ -404,6 +421,8 @@ def main():
                 "frac_one_sweep_equiv": round(one_sweep_equiv / HBM_PEAK_GBS, 4),
                 "copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
                 "copy_bw_frac": round(achieved / copy_gbs, 4) if copy_gbs else None,
+                "two_application_launches": (prof.two_launches if prof else 0),
+                "single_sweep_launches": (prof.single_launches if prof else None),
             },
         }
         if world == 1 and not args.no_cpu_baseline and not bf16:

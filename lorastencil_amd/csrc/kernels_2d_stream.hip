@@ -39,7 +39,10 @@ namespace lora {
 namespace {
 
 constexpr int kSInW = 128;   // input columns per strip: one 16-byte piece per lane
-constexpr int kBRow = 136;   // doubles of an intermediate row buffer (lanes past the valid range read slack)
+constexpr int kBRow = 128;   // doubles of an intermediate row buffer; window reads of the lanes past a level's valid range
+                             // run up to 6 doubles into whatever follows (the next row buffer, the next wave's ring,
+                             // kLdsSlack at the end of the workgroup's allocation): never used, only has to be mapped
+constexpr int kLdsSlack = 8;
 
 // K applications per launch: every level shifts the lane -> column map by 3, so a strip yields 128 - 6 K output columns
 // (116 for K = 2, 104 for K = 4) from its 128 input columns.
@@ -82,7 +85,9 @@ __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel
     constexpr int WLDS = stream_wave_lds(K);
     static_assert(K == 2 || K == 4, "applications per launch");
     static_assert(D >= 2 && D <= 6 && (K == 2 || D <= 3) && (!DIRI || (K == 2 && D <= 4)), "rows in flight");
-    __shared__ __attribute__((aligned(16))) double lds[4 * WLDS];
+    // K = 4: 4 x 13 KB + slack = 53,312 B -- three workgroups per CU need <= 53,760 B each (the 160 KB are handed out in
+    // 1,280-byte granules: at 54,016 B only two were resident, PMC occupancy 1.74 of 3 waves per SIMD)
+    __shared__ __attribute__((aligned(16))) double lds[4 * WLDS + kLdsSlack];
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -58,6 +58,8 @@ def test_bench_line_roofline_is_a_fraction():
     d = json.loads(lines[-1])
     rf = d["roofline"]
     assert d["n_gpus"] == 1 and 0 < rf["frac"] <= 1.0 and rf["applications_per_launch"] == 4
-    assert abs(rf["frac_one_sweep_equiv"] - 4 * rf["frac"]) < 1e-3 and rf["launches"] == 2
+    assert 0 < rf["hbm"]["frac"] <= 1.0 and 0 < rf["fp64"]["frac"] <= 1.0
+    assert rf["frac"] == max(rf["hbm"]["frac"], rf["fp64"]["frac"]) and rf["bound"] in ("hbm", "mfma")
+    assert abs(rf["frac_one_sweep_equiv"] - 4 * rf["hbm"]["frac"]) < 1e-3 and rf["launches"] == 2
     assert rf["traffic"] is None or rf["traffic_key"].endswith(rf["kernel"])  # never a number of another kernel
     assert d["cpu_baseline"]["cores"] >= 1

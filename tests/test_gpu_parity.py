@@ -252,7 +252,7 @@ def test_fused_lowrank_evaluation_on_the_vector_pipe(L, O):
     then vertical scatter) when the factors fit; forcing the direct taps must give the same grid."""
     import torch
 
-    for shape, expect_eval in (("star2d1r", 3), ("box2d3r", 6), ("box2d1r", 6), ("star2d3r", 1)):
+    for shape, expect_eval in (("star2d1r", 7), ("box2d3r", 6), ("box2d1r", 6), ("star2d3r", 1)):
         dims = (150, 380)
         a = O.reference_input(shape, dims)
         exp = O.run(shape, a, 4)
@@ -263,6 +263,7 @@ def test_fused_lowrank_evaluation_on_the_vector_pipe(L, O):
             assert np.array_equal(plan_run(L, shape, a, 4, options={**k, "lowrank_valu": 0}), exp), shape
             assert np.array_equal(plan_run(L, shape, a, 4, options={**k, "lowrank_valu": 2}), exp), shape  # plain pyramid form
             assert np.array_equal(plan_run(L, shape, a, 4, options={**k, "lowrank_valu": 3}), exp), shape  # symmetric, no gap
+            assert np.array_equal(plan_run(L, shape, a, 4, options={**k, "lowrank_valu": 4}), exp), shape  # rank 1 + correction
         off = L.Plan(shape, dims).set_option("lowrank_valu", 0)
         assert off.get_option("fused_eval") == {"star2d1r": 0, "box2d3r": 2, "box2d1r": 2, "star2d3r": 1}[shape]
     # scaled star2d1r taps keep the form; real-valued data within rounding of the oracle
@@ -270,7 +271,11 @@ def test_fused_lowrank_evaluation_on_the_vector_pipe(L, O):
     a = rng.standard_normal(O.padded_shape("star2d1r", (128, 512)))
     w = O.effective_weights("star2d1r") / 100.0
     plan = L.Plan("star2d1r", (128, 512)).set_weights(w)
-    assert plan.get_option("fused_eval") == 3
+    assert plan.get_option("fused_eval") == 7  # nested-profile form: rows (1), 2 (1 2 1), 2 (1 2 4 2 1), (1 4 8 16 8 4 1)
+    assert L.Plan("star2d1r", (128, 512)).set_weights(w).set_option("lowrank_valu", 4).get_option("fused_eval") == 3
+    for lr in (-1, 4):
+        got = plan_run(L, "star2d1r", a, 8, weights=w, options={"lowrank_valu": lr})
+        assert rel_err(got, O.run("star2d1r", a, 8, weights=w)) < 1e-13
     assert rel_err(plan_run(L, "star2d1r", a, 8, weights=w), O.run("star2d1r", a, 8, weights=w)) < 1e-13
     # a rank-4 box table (centre 10): the residual tap rules the pyramid form out, direct taps are used
     p4 = O.default_params("box2d3r").copy()
