@@ -166,6 +166,11 @@ int lora_plan_set_boundary(lora_plan *plan, int boundary);
 /* Boundary condition given to plans created afterwards on this thread, i.e. also to the host operators of group A
  * (what the CLIs' --bc flag sets).  Returns the previous value. */
 int lora_set_default_boundary(int boundary);
+/* Normalised-weights mode for plans created afterwards on this thread, i.e. also for the host operators of group A
+ * (what the CLIs' --normalize flag sets): the operator's effective taps are divided by their sum, so that runs longer
+ * than the fp64 range of the reference's integer taps allows stay finite (box2d3r overflows at step ~129, SURVEY B7;
+ * BASELINE config 3 asks for 200).  Not reference behaviour.  Returns the previous value. */
+int lora_set_default_normalize(int on);
 /* Integer options.  Results never depend on them except where stated.
  *   steps_per_launch  0 auto / 1 / 2 (2D also 4 with the row-streaming kernel, 1D also 4, 8) : applications per launch
  *                     in lora_plan_run (temporal fusion)
@@ -240,6 +245,90 @@ typedef struct lora_run_profile {
 int lora_plan_run_profiled(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream,
                            lora_run_profile *profile);
 void lora_plan_destroy(lora_plan *plan);
+
+/* ========================================================================================
+ * D. Multi-GPU slabs (NEW: the reference is single-GPU).  The grid is cut along its outermost interior
+ *    dimension into one slab per GPU; the time-step loop (2d/gpu.cu:544-546) runs on every slab with a nearest-
+ *    neighbour ghost-zone exchange over RCCL (ncclSend / ncclRecv in one group, on a communication stream) overlapped
+ *    with the interior sweeps.  N slabs == 1 GPU bit for bit (same kernels, same per-point arithmetic).
+ *    Usual form: one process per GPU, each creating ONE slab with its rank and an RCCL communicator; the CLIs' --gpus N
+ *    drive N slabs of one process (lora_run_host_multi).
+ * ====================================================================================== */
+typedef struct lora_slab lora_slab;
+
+/* How neighbouring slabs exchange ghost rows.  All calls are made from the driving host thread; send / recv enqueue on
+ * `stream` (a hipStream_t) and must not block the host; every exchange of a launch sits between one group_begin and
+ * one group_end (called on the first slab's table).  `peer` is a rank of the decomposition. */
+typedef struct lora_slab_comm {
+    void *ctx;
+    int (*group_begin)(void *ctx);
+    int (*send)(void *ctx, const void *d_buf, size_t bytes, int peer, void *stream);
+    int (*recv)(void *ctx, void *d_buf, size_t bytes, int peer, void *stream);
+    int (*group_end)(void *ctx);
+} lora_slab_comm;
+/* RCCL: ctx = an ncclComm_t of this rank (ncclCommInitRank / ncclCommInitAll, or torch's); librccl.so is loaded on
+ * first use, the engine library does not link it. */
+int lora_slab_comm_rccl(lora_slab_comm *out, void *nccl_comm);
+/* In-process loopback for `nranks` slabs that live in ONE process on ONE device: messages become device-to-device
+ * copies ordered by events.  Fills out[0 .. nranks-1].  For tests / rehearsals on a one-GPU box. */
+int lora_slab_comm_loopback(lora_slab_comm *out, int nranks);
+
+enum lora_slab_flags {
+    LORA_SLAB_NO_OVERLAP = 1,  /* sweep the whole slab, then exchange (no boundary-first split)              */
+    LORA_SLAB_NO_DEFER = 2,    /* wait for an exchange at the end of its launch instead of inside the next   */
+    LORA_SLAB_NO_FUSION = 4,   /* single sweeps only                                                         */
+    LORA_SLAB_RING_OF_ONE = 8  /* nranks == 1: the slab is its own neighbour (periodic along the split
+                                  dimension) -- the complete exchange path on one GPU; with the reference boundary
+                                  a rehearsal of one rank's share of an N-GPU run, not a physical result      */
+};
+typedef struct lora_slab_desc {
+    int shape, dtype;          /* lora_shape, lora_dtype                                                      */
+    int global_dims[3];        /* interior extents of the WHOLE grid, outermost first                         */
+    const double *params;      /* as lora_plan_create (NULL: the reference harness's table)                   */
+    const double *weights;     /* nullable: taps applied per sweep, bypassing the params mapping              */
+    int rank, nranks;          /* this slab and the number of slabs (GPUs)                                    */
+    int device;                /* HIP device the slab lives on                                                */
+    int exchange_every;        /* launches between ghost-zone refreshes; 0 = auto (8 / 4 / 2 / 1 by slab thickness) */
+    int boundary;              /* LORA_BC_REFERENCE or LORA_BC_DIRICHLET                                      */
+    int flags;                 /* lora_slab_flags                                                             */
+    const char *options;       /* nullable "key=value,key=value": plan options, applied before the ghost depth is fixed */
+} lora_slab_desc;
+typedef struct lora_slab_info_t {
+    int begin, end;            /* global interior range of the slab's own rows                                */
+    int ghost, ghost_top, ghost_bottom;
+    int apps_per_launch, exchange_every, steps_done;
+    int local_dims[3];         /* interior extents of the local array (own + ghost rows)                      */
+    long launches, exchanges;
+    size_t local_bytes;        /* bytes of one local padded buffer                                            */
+} lora_slab_info_t;
+
+/* `comm` may be NULL for nranks == 1 without the ring flag.  Allocates the slab's two local buffers and streams. */
+int lora_slab_create(lora_slab **slab, const lora_slab_desc *desc, const lora_slab_comm *comm);
+void lora_slab_destroy(lora_slab *slab);
+int lora_slab_info(const lora_slab *slab, lora_slab_info_t *info);
+/* buffer 0 <- this slab's rows of the padded GLOBAL host array (ghost rows and pads included), buffer 1 <- 0 */
+int lora_slab_load(lora_slab *slab, const void *host_global_padded);
+/* the same from a LOCAL padded device array (own + ghost rows + pads), e.g. data generated on the device;
+ * call lora_slab_refresh_ghosts afterwards */
+int lora_slab_load_device(lora_slab *slab, const void *d_local_padded);
+int lora_slab_refresh_ghosts(lora_slab *slab);
+/* `times` kernel applications (fused launches from even time levels, single sweeps otherwise); asynchronous */
+int lora_slab_run(lora_slab *slab, int times);
+int lora_slab_sync(lora_slab *slab);
+/* own rows (+ the pad rows at a global edge) of the current time level -> their place in the padded GLOBAL host array */
+int lora_slab_store(lora_slab *slab, void *host_global_padded);
+/* which = 0 / 1: the two local device buffers; anything else: the one holding the current time level */
+void *lora_slab_buffer(lora_slab *slab, int which);
+void *lora_slab_stream(lora_slab *slab); /* the hipStream_t its sweeps run on */
+lora_plan *lora_slab_plan(lora_slab *slab);
+/* Several slabs of ONE decomposition driven by this host thread (one process, N devices): launches and exchanges are
+ * interleaved across the slabs, every exchange inside one group. */
+int lora_slab_run_many(lora_slab **slabs, int n, int times);
+int lora_slab_refresh_ghosts_many(lora_slab **slabs, int n);
+/* Group A's generic operator on `ngpus` devices of this node: one slab per device, RCCL from ncclCommInitAll.
+ * (LORA_SLAB_LOOPBACK=1 in the environment: all slabs on device 0 with the loopback exchange -- one-GPU rehearsal.) */
+int lora_run_host_multi(int shape, int dtype, const void *in, void *out, const double *params, int times,
+                        const int *dims, int ngpus, int quiet, lora_run_info *info);
 
 /* ========================================================================================
  * C. Host helpers on the path.

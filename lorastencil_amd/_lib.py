@@ -62,6 +62,33 @@ class RunProfile(ctypes.Structure):
     ]
 
 
+_comm_begin_t = ctypes.CFUNCTYPE(ctypes.c_int, _vp)
+_comm_xfer_t = ctypes.CFUNCTYPE(ctypes.c_int, _vp, _vp, ctypes.c_size_t, ctypes.c_int, _vp)
+
+
+class SlabComm(ctypes.Structure):
+    """lora_slab_comm: the neighbour-exchange callbacks of the C++ slab driver."""
+    _fields_ = [("ctx", _vp), ("group_begin", _comm_begin_t), ("send", _comm_xfer_t), ("recv", _comm_xfer_t),
+                ("group_end", _comm_begin_t)]
+
+
+class SlabDesc(ctypes.Structure):
+    _fields_ = [("shape", ctypes.c_int), ("dtype", ctypes.c_int), ("global_dims", ctypes.c_int * 3), ("params", _dp),
+                ("weights", _dp), ("rank", ctypes.c_int), ("nranks", ctypes.c_int), ("device", ctypes.c_int),
+                ("exchange_every", ctypes.c_int), ("boundary", ctypes.c_int), ("flags", ctypes.c_int),
+                ("options", ctypes.c_char_p)]
+
+
+class SlabInfo(ctypes.Structure):
+    _fields_ = [("begin", ctypes.c_int), ("end", ctypes.c_int), ("ghost", ctypes.c_int), ("ghost_top", ctypes.c_int),
+                ("ghost_bottom", ctypes.c_int), ("apps_per_launch", ctypes.c_int), ("exchange_every", ctypes.c_int),
+                ("steps_done", ctypes.c_int), ("local_dims", ctypes.c_int * 3), ("launches", ctypes.c_long),
+                ("exchanges", ctypes.c_long), ("local_bytes", ctypes.c_size_t)]
+
+
+SLAB_NO_OVERLAP, SLAB_NO_DEFER, SLAB_NO_FUSION, SLAB_RING_OF_ONE = 1, 2, 4, 8
+
+
 class Rng(ctypes.Structure):
     _fields_ = [("r", ctypes.c_int32 * 34), ("pos", ctypes.c_int32)]
 
@@ -97,9 +124,28 @@ SIGNATURES = {
     "lora_plan_set_variant": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lora_plan_set_boundary": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lora_set_default_boundary": (ctypes.c_int, [ctypes.c_int]),
+    "lora_set_default_normalize": (ctypes.c_int, [ctypes.c_int]),
     "lora_plan_set_option": (ctypes.c_int, [_vp, ctypes.c_char_p, ctypes.c_int]),
     "lora_plan_get_option": (ctypes.c_int, [_vp, ctypes.c_char_p, _ip]),
     "lora_plan_kernel_signature": (ctypes.c_char_p, [_vp]),
+    "lora_slab_comm_rccl": (ctypes.c_int, [ctypes.POINTER(SlabComm), _vp]),
+    "lora_slab_comm_loopback": (ctypes.c_int, [ctypes.POINTER(SlabComm), ctypes.c_int]),
+    "lora_slab_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(SlabDesc), ctypes.POINTER(SlabComm)]),
+    "lora_slab_destroy": (None, [_vp]),
+    "lora_slab_info": (ctypes.c_int, [_vp, ctypes.POINTER(SlabInfo)]),
+    "lora_slab_load": (ctypes.c_int, [_vp, _vp]),
+    "lora_slab_load_device": (ctypes.c_int, [_vp, _vp]),
+    "lora_slab_refresh_ghosts": (ctypes.c_int, [_vp]),
+    "lora_slab_run": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lora_slab_sync": (ctypes.c_int, [_vp]),
+    "lora_slab_store": (ctypes.c_int, [_vp, _vp]),
+    "lora_slab_buffer": (_vp, [_vp, ctypes.c_int]),
+    "lora_slab_stream": (_vp, [_vp]),
+    "lora_slab_plan": (_vp, [_vp]),
+    "lora_slab_run_many": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int]),
+    "lora_slab_refresh_ghosts_many": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int]),
+    "lora_run_host_multi": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _dp, ctypes.c_int, _ip, ctypes.c_int,
+                                           ctypes.c_int, ctypes.POINTER(RunInfo)]),
     "lora_plan_run_profiled": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.POINTER(RunProfile)]),
     "lora_plan_padded_bytes": (ctypes.c_size_t, [_vp]),
     "lora_plan_kernel_name": (ctypes.c_char_p, [_vp]),

@@ -23,11 +23,15 @@ namespace lora {
 
 static thread_local std::string g_last_error;
 static thread_local int g_default_boundary = LORA_BC_REFERENCE;
+static thread_local int g_default_normalize = 0;
 static thread_local lora_run_info g_last_info = {};
 
 void set_last_error(const char *what, hipError_t e) {
     g_last_error = std::string(what) + ": " + hipGetErrorName(e) + " (" + hipGetErrorString(e) + ")";
 }
+
+void set_last_error_text(const char *text) { g_last_error = text ? text : ""; }
+void set_last_run_info(const lora_run_info &info) { g_last_info = info; }
 
 #define LORA_HIP_TRY(expr)                      \
     do {                                        \
@@ -328,6 +332,7 @@ static int step_region(Plan &p, const void *d_in, void *d_out, int begin, int en
 }  // namespace lora
 
 using lora::g_default_boundary;
+using lora::g_default_normalize;
 using lora::g_last_error;
 using lora::Plan;
 
@@ -404,6 +409,12 @@ int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, con
         params = tmp;
     }
     lora::effective_weights(shape, params, p.w);
+    if (g_default_normalize) {  // normalised-weights mode: the operator's taps divided by their sum
+        double sum = 0.0;
+        for (int k = 0; k < p.ntaps; ++k) sum += p.w[k];
+        if (sum != 0.0 && std::isfinite(sum))
+            for (int k = 0; k < p.ntaps; ++k) p.w[k] /= sum;
+    }
     p.variant = LORA_VARIANT_DIRECT;
     p.generic = odd_inner;
     p.boundary = g_default_boundary;
@@ -444,6 +455,12 @@ int lora_plan_get_weights(const lora_plan *plan, double *weights, int count) {
 int lora_set_default_boundary(int boundary) {
     const int old = g_default_boundary;
     if (boundary >= LORA_BC_REFERENCE && boundary <= LORA_BC_PERIODIC) g_default_boundary = boundary;
+    return old;
+}
+
+int lora_set_default_normalize(int on) {
+    const int old = g_default_normalize;
+    g_default_normalize = on ? 1 : 0;
     return old;
 }
 
@@ -1086,3 +1103,7 @@ int lora_gpu_star_3d1r(const double *in, double *out, const double *params, int 
 }
 
 }  // extern "C"
+
+namespace lora {
+const char *run_label(int shape) { return ::run_label(shape); }
+}  // namespace lora

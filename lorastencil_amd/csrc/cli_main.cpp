@@ -9,6 +9,10 @@
 //   --fill=random|index|ones   the reference's FILL_RANDOM / FILL_INDEX / default fills (compile-time macros there)
 //   --no-extra         print nothing beyond the reference's own lines
 //   --bc=reference|dirichlet|periodic   boundary condition of the time-step driver (default: the reference's)
+//   --normalize                         taps / sum(taps): stays finite for any step count (box2d3r x200 overflows
+//                                       fp64 with the reference's integer taps); not reference behaviour
+//   --gpus=N           cut the grid into N slabs, one per GPU of this node, with RCCL ghost-zone exchange
+//                      (lora_run_host_multi; the reference is single-GPU)
 //   --dtype=bf16       (lorastencil_3d only) store the grid in bf16, accumulate in fp32 (BASELINE config 5; new)
 #include <cstdio>
 #include <cstdlib>
@@ -122,8 +126,9 @@ int main(int argc, char *argv[]) {
         return 1;
     }
 
-    bool check = false, extra = true, bf16 = false, custom_bc = false;
+    bool check = false, extra = true, bf16 = false, custom_bc = false, normalize = false;
     Fill fill = Fill::Random;
+    int gpus = 1;
     for (int i = kDim + 3; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--check")
@@ -141,6 +146,21 @@ int main(int argc, char *argv[]) {
         else if (a == "--bc=dirichlet" || a == "--bc=periodic") {
             lora_set_default_boundary(a == "--bc=dirichlet" ? LORA_BC_DIRICHLET : LORA_BC_PERIODIC);
             custom_bc = true;
+        }
+        else if (a == "--normalize") {
+            lora_set_default_normalize(1);  // taps / sum(taps): finite for any number of steps
+            normalize = true;
+        }
+        else if (a.rfind("--gpus=", 0) == 0) {
+            try {
+                gpus = std::stoi(a.substr(7));
+            } catch (const std::exception &) {
+                gpus = 0;
+            }
+            if (gpus < 1) {
+                std::cerr << "Invalid argument: --gpus=N needs a positive integer.\n";
+                return 1;
+            }
         }
         else if (a == "--dtype=f64")
             bf16 = false;
@@ -178,19 +198,29 @@ int main(int argc, char *argv[]) {
     std::vector<double> matrix(count, 0.0), output(count, 0.0);
     fill_input(matrix, shape, dims, fill);
 
-    if (check && custom_bc) {
-        std::cerr << "--check compares with the reference's boundary behaviour; ignored with --bc\n";
+    if (check && (custom_bc || normalize)) {
+        std::cerr << "--check compares with the reference's boundary behaviour and taps; ignored with --bc / --normalize\n";
         check = false;
     }
     if (check) {  // CHECK_ERROR prints the shape and the params first (2d/main.cu:257-265)
         std::cout << argv[1] << std::endl;
     }
 
-    if (bf16) {
+    if (gpus > 1 && !bf16) {
+        // N slabs, one per GPU; prints the reference's three lines like the single-GPU operator
+        const int rc = lora_run_host_multi(shape, LORA_F64, matrix.data(), output.data(), params, times, dims, gpus, 0, nullptr);
+        if (rc != LORA_OK) {
+            std::printf("LoRAStencil HIP Error: %s %s\n", lora_strerror(rc), lora_last_error());
+            return 1;
+        }
+        if (extra) std::printf("GPUs = %d (row / plane slabs, RCCL ghost-zone exchange)\n", gpus);
+    } else if (bf16) {
         // values 0..99 are exact in bf16; the operator prints the reference's three lines itself
         std::vector<uint16_t> in16(count), out16(count, 0);
         lora_f64_to_bf16(matrix.data(), in16.data(), count);
-        const int rc = lora_run_host_dtype(shape, LORA_BF16, in16.data(), out16.data(), params, times, dims, 0, nullptr);
+        const int rc = gpus > 1 ? lora_run_host_multi(shape, LORA_BF16, in16.data(), out16.data(), params, times, dims,
+                                                      gpus, 0, nullptr)
+                                : lora_run_host_dtype(shape, LORA_BF16, in16.data(), out16.data(), params, times, dims, 0, nullptr);
         if (rc != LORA_OK) {
             std::printf("LoRAStencil HIP Error: %s %s\n", lora_strerror(rc), lora_last_error());
             return 1;
@@ -223,6 +253,7 @@ int main(int argc, char *argv[]) {
             break;
     }
 
+    if (extra && normalize) std::printf("Taps normalised (weights / sum of weights)\n");
     if (extra) {
         lora_run_info ri;
         if (lora_last_run_info(&ri) == LORA_OK && ri.sweep_seconds > 0) {
@@ -231,6 +262,18 @@ int main(int argc, char *argv[]) {
                         bf16 ? " [bf16 storage]" : "");
             std::printf("Total incl. transfers = %f s\n", ri.total_seconds);
         }
+        // value range of the returned array (all of it: interior and the halo state): shows an overflowed run at once
+        double lo = output.empty() ? 0.0 : output[0], hi = lo;
+        bool finite = true;
+        for (double v : output) {
+            if (!(v - v == 0.0)) finite = false;  // NaN or infinity
+            lo = v < lo ? v : lo;
+            hi = v > hi ? v : hi;
+        }
+        if (finite)
+            std::printf("Result range = [%g, %g]\n", lo, hi);
+        else
+            std::printf("Result range = not finite (overflow: see --normalize)\n");
     }
 
     if (check) {

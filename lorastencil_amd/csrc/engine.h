@@ -127,6 +127,9 @@ const char *kernel_name_3d(const Plan &p);
 int region_granularity(const Plan &p);
 
 void set_last_error(const char *what, hipError_t e);
+void set_last_error_text(const char *text);
+void set_last_run_info(const lora_run_info &info);  // what lora_last_run_info returns on this thread
+const char *run_label(int shape);                  // the operator's first stdout line (e.g. 2d/gpu.cu:549)
 
 }  // namespace lora
 

@@ -234,12 +234,14 @@ def test_diagnostics_are_not_in_the_shipped_library(L, monkeypatch):
 
 def test_kernel_signature_names_every_selecting_option(L):
     p = L.Plan("star2d1r", (16384, 16384))
-    assert p.kernel_signature.startswith(p.kernel_name + "[") and "eval=3" in p.kernel_signature
+    assert p.kernel_name == "stencil2d_stream_kernel"  # the default 2D kernel: row-streaming, four applications
+    assert p.kernel_signature.startswith(p.kernel_name + "[") and "eval=7" in p.kernel_signature
+    assert "k=4" in p.kernel_signature and "depth=" in p.kernel_signature and "rows=" in p.kernel_signature
     s0 = p.kernel_signature
     p.set_option("lowrank_valu", 0)
     assert p.kernel_signature != s0  # another instantiation: measured traffic filed under s0 no longer applies
-    p.set_option("stream", 1)
-    assert p.kernel_name == "stencil2d_stream_kernel" and "depth=" in p.kernel_signature and "rows=" in p.kernel_signature
+    p.set_option("stream", 0)
+    assert p.kernel_name == "stencil2d_fused2_kernel" and "rows=10" in p.kernel_signature
     assert L.Plan("1d1r", (4096,)).kernel_signature == "stencil1d_fusedk_kernel[k=8]"
     with pytest.raises(L.LoraError):
         L.Plan("1d1r", (2**31 - 8,))  # padded extent n + 8 would overflow the kernels' 32-bit indices

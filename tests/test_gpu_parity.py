@@ -1096,6 +1096,52 @@ def test_cli_runs_and_self_check_passes(L, dim, args):
     assert not any(l.startswith(("row = ", "col = ", "height = ")) for l in lines)
 
 
+def test_cli_normalize_keeps_config_3_finite(L):
+    """BASELINE config 3 (`box2d3r 8192 8192 200`) overflows fp64 with the reference's integer taps (sum 232: NaN from
+    step ~129); --normalize (taps / sum) keeps the same run finite from the reference's own surface.  Run
+    here at 1024 x 1024: the horizon depends on the step count, not on the size."""
+    exe = os.path.join(ROOT, "lorastencil_amd", "bin", "lorastencil_2d")
+    rc, out, err = _run([exe, "box2d3r", "1024", "1024", "200", "--normalize"])
+    assert rc == 0, out + err
+    rng = [l for l in out.splitlines() if l.startswith("Result range = ")]
+    assert "Taps normalised" in out and len(rng) == 1 and rng[0].startswith("Result range = [") and "not finite" not in out
+    rc, out_u, err = _run([exe, "box2d3r", "1024", "1024", "200"])
+    assert rc == 0 and "Result range = not finite" in out_u  # the reference's taps overflow, like the reference itself
+    # through the library: same switch, result finite and equal to the oracle with normalised taps
+    from lorastencil_amd import _lib
+
+    _lib.lib().lora_set_default_normalize(1)
+    try:
+        a = L.reference_input("box2d3r", (96, 128))
+        out_n, _ = L.run_host("box2d3r", a, times=200, quiet=True)
+    finally:
+        _lib.lib().lora_set_default_normalize(0)
+    assert np.isfinite(out_n).all()
+    out_u, _ = L.run_host("box2d3r", a, times=200, quiet=True)
+    assert not np.isfinite(out_u).all()  # the reference's taps: overflowed, like the reference itself
+
+
+@pytest.mark.parametrize("shape,dims", [("star2d1r", (4096, 4096)), ("box2d3r", (2048, 2048)), ("star3d1r", (256, 256, 256)),
+                                        ("box3d1r", (256, 256, 256))])
+def test_hundred_steps_on_a_large_grid_match_the_oracle(L, O, shape, dims):
+    """One long run on a grid large enough to span many chunks / panels, every XCD's share and the whole default
+    schedule (2D: 24 four-application launches + 2 two-application ones; 3D: 50 two-application launches), normalised
+    taps, default options, hipGraph off -- against the oracle (all host threads) at the north star's 1e-10."""
+    w = O.effective_weights(shape)
+    w = w / w.sum()
+    a = O.reference_input(shape, dims) if len(dims) == 2 else \
+        np.random.default_rng(5).integers(0, 100, O.padded_shape(shape, dims)).astype(np.float64)
+    got = plan_run(L, shape, a, 100, weights=w, options={"graph": 0})
+    exp = O.run(shape, a, 100, weights=w, threads=O.max_threads())
+    assert np.isfinite(exp).all()
+    assert rel_err(got, exp) < REL_TOL
+    g_i, e_i = O.interior(shape, got), O.interior(shape, exp)
+    assert np.abs(g_i - e_i).max() <= REL_TOL * np.abs(e_i).max()
+    h = L.ops.halo(shape)
+    edge = tuple(slice(0, k) for k in h)
+    assert np.array_equal(got[edge], exp[edge])  # the halo state after an even number of steps: the input's
+
+
 @pytest.mark.parametrize("dim,args", [(1, ["1d1r", "4096", "3"]), (2, ["star2d1r", "64", "128", "3"]),
                                       (2, ["box2d3r", "32", "64", "2"]), (2, ["star2d3r", "32", "64", "1"]),
                                       (3, ["star3d1r", "8", "16", "128", "2"]), (3, ["box3d1r", "8", "8", "64", "1"])])
