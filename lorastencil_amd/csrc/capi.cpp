@@ -271,16 +271,29 @@ void plan_refresh(Plan &p) {
             if ((dz != 1) + (dy != 1) + (dx != 1) > 1) star = false;
         }
         p.tapset = star ? TAPS3D_STAR : TAPS3D_BOX;
-        if (!star && p.dtype == LORA_BF16 && p.separable != 0) {
-            float w32[27];
+        p.mfma3_valid = false;
+        if (!star && p.dtype == LORA_BF16) {
+            float w32[27], cba[9];
             for (int k = 0; k < 27; ++k) w32[k] = (float) p.w[k];
-            if (separable_27(w32, p.sep)) p.tapset = TAPS3D_SEP;
+            if (separable_27(w32, cba)) {
+                if (p.separable != 0) {
+                    p.tapset = TAPS3D_SEP;
+                    for (int k = 0; k < 9; ++k) p.sep[k] = cba[k];
+                }
+                p.mfma3_valid = mfma_factors_27(cba, &p.mfma3_scale, p.mfma3_abc) != 0;
+            }
         }
+        // the matrix-pipe variant exists for bf16 box taps with bf16-exact factors, reference boundary, fused launches
+        if (p.variant == LORA_VARIANT_MFMA &&
+            !(p.dtype == LORA_BF16 && p.mfma3_valid && p.boundary == LORA_BC_REFERENCE && p.steps_per_launch_req != 1))
+            p.variant = LORA_VARIANT_DIRECT;
         // two applications per launch (kernels_3d_fused.hip): fp64 tiled path; default, as in 2D (star3d1r 512^3
         // 499 vs 288 GStencils/s, box3d1r 768^3 523 vs 300)
         p.steps_per_launch = (!p.generic && p.steps_per_launch_req != 1) ? 2 : 1;
         p.kernel_name = (p.dtype == LORA_BF16)
-                            ? (p.steps_per_launch == 2 ? kernel_name_3d_bf16_fused2(p) : kernel_name_3d_bf16(p))
+                            ? (p.steps_per_launch == 2 ? (p.variant == LORA_VARIANT_MFMA ? kernel_name_3d_bf16_mfma2(p)
+                                                                                          : kernel_name_3d_bf16_fused2(p))
+                                                       : kernel_name_3d_bf16(p))
                         : p.generic            ? kernel_name_generic(p)
                         : p.steps_per_launch == 2 ? kernel_name_3d_fused2(p)
                                                   : kernel_name_3d(p);
@@ -483,9 +496,17 @@ int lora_plan_set_boundary(lora_plan *plan, int boundary) {
 int lora_plan_set_variant(lora_plan *plan, int variant) {
     if (!plan) return LORA_EINVAL;
     if (variant == LORA_VARIANT_AUTO) variant = LORA_VARIANT_DIRECT;
-    if (variant == LORA_VARIANT_MFMA && plan->p.ndim != 2) return LORA_EUNSUPPORTED;
     if (variant != LORA_VARIANT_DIRECT && variant != LORA_VARIANT_MFMA) return LORA_EINVAL;
-    if (variant == LORA_VARIANT_MFMA && !plan->p.lowrank_valid) {
+    if (variant == LORA_VARIANT_MFMA && plan->p.ndim == 3) {
+        // bf16 box taps: in-plane passes on v_mfma_f32_16x16x32_bf16 (kernels_3d_bf16_mfma.hip)
+        const Plan &q = plan->p;
+        if (!(q.dtype == LORA_BF16 && q.mfma3_valid && q.boundary == LORA_BC_REFERENCE && q.steps_per_launch_req != 1)) {
+            g_last_error = "the bf16 MFMA variant takes separable box taps with bf16-exact factors, reference boundary, fused launches";
+            return LORA_EUNSUPPORTED;
+        }
+    } else if (variant == LORA_VARIANT_MFMA && plan->p.ndim != 2) {
+        return LORA_EUNSUPPORTED;
+    } else if (variant == LORA_VARIANT_MFMA && !plan->p.lowrank_valid) {
         g_last_error = "these taps have no rank<=3 + sparse-residual factorisation";
         return LORA_EUNSUPPORTED;
     }
@@ -521,6 +542,8 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "stream_sync")) {
         if (value < 0 || value > 2) return LORA_EINVAL;
         p.stream_sync = value;
+    } else if (!std::strcmp(key, "mfma_split")) {
+        p.mfma_split = value ? 1 : 0;
     } else if (!std::strcmp(key, "graph")) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.use_graph = value;
@@ -684,7 +707,9 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
                                                                    static_cast<double *>(d_out), begin, end,
                                                                    static_cast<hipStream_t>(stream)))
                          : p.dtype == LORA_BF16
-                             ? lora::launch_3d_bf16_fused2(p, d_in, d_out, begin, end, static_cast<hipStream_t>(stream))
+                             ? (p.variant == LORA_VARIANT_MFMA
+                                    ? lora::launch_3d_bf16_mfma2(p, d_in, d_out, begin, end, static_cast<hipStream_t>(stream))
+                                    : lora::launch_3d_bf16_fused2(p, d_in, d_out, begin, end, static_cast<hipStream_t>(stream)))
                              : lora::launch_3d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),
                                                       begin, end, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) {
@@ -870,7 +895,7 @@ int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *
     // stream (not the legacy default one), no capture already in progress, and kernels that do no host-side work
     // at launch (the MFMA variant uploads its band tables).
     bool want = p.use_graph == 1 || (p.use_graph < 0 && times >= 16 && lora_plan_padded_bytes(plan) <= (64u << 20));
-    if (want && (s == nullptr || p.variant == LORA_VARIANT_MFMA)) want = false;
+    if (want && s == nullptr) want = false;
     if (want) {
         hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(s, &st) != hipSuccess || st != hipStreamCaptureStatusNone) {

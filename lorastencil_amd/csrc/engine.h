@@ -18,6 +18,7 @@ int effective_weights(int shape, const double *params, double *weights);
 int factorize_7x7(const double *params, double u[4][7], double v[4][7], double *residual_max);
 int svd_7x7(const double *W, double u[7][7], double v[7][7], double sigma[7]);
 int separable_27(const float *w27, float *cba9);  // exact rank-1 test of fp32 3x3x3 taps; cba = c(x), b(y), a(z)
+int mfma_factors_27(const float *cba9, float *scale, float *cba9_normalised);  // bf16-exact normalised factors or 0
 
 // ---- tap sets: which of the 49 / 27 taps a kernel instantiation evaluates --------------------
 enum TapSet2D { TAPS2D_DIAMOND = 0, TAPS2D_STAR = 1, TAPS2D_BOX = 2 };
@@ -60,6 +61,9 @@ struct Plan {
     int cols_per_lane = 4;    // 3D bf16: 4 (512-byte row pieces per wave) or 8 (1 KiB)
     int separable = -1;       // 3D bf16: evaluate exactly-separable taps as x/y/z passes: -1 auto (= on), 0 off
     float sep[9] = {0};       // resolved factors c(x), b(y), a(z) when tapset == TAPS3D_SEP
+    int mfma_split = 1;       // bf16 MFMA variant: intermediate as hi + lo bf16 halves (1, the contract) or one bf16 rounding (0)
+    bool mfma3_valid = false; // bf16: the taps are scale * a (x) b (x) c with bf16-exact normalised factors (MFMA variant)
+    float mfma3_scale = 0.0f, mfma3_abc[9] = {0};  // normalised c, b, a
     int ablate = 0;           // diagnostics only (2D fused, 3D bf16): 1 = skip stores, 2 = skip loads; results wrong
     int lds_dma = 0;          // 3D bf16: global_load_lds ring, two planes ahead (hand-counted vmcnt)
     int persistent = 0;       // 2D fused: persistent workgroups with register prefetch of the next tile
@@ -119,6 +123,9 @@ hipError_t launch_3d_bf16(const Plan &p, const void *in, void *out, int begin, i
 const char *kernel_name_3d_bf16(const Plan &p);
 hipError_t launch_3d_bf16_fused2(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s);
 const char *kernel_name_3d_bf16_fused2(const Plan &p);
+// bf16 box, two applications per launch, in-plane passes on v_mfma_f32_16x16x32_bf16 (LORA_VARIANT_MFMA)
+hipError_t launch_3d_bf16_mfma2(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s);
+const char *kernel_name_3d_bf16_mfma2(const Plan &p);
 
 const char *kernel_name_1d(const Plan &p);
 const char *kernel_name_2d_direct(const Plan &p);

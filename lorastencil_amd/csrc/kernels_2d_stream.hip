@@ -18,10 +18,10 @@
 //   * the seven partially summed rows of each level live in rotating register files (the loop is unrolled by 7 so
 //     that the rotation is a compile-time renaming, apply_row<.., ROT>);
 //   * no workgroup barriers on the data path: a wave's own LDS traffic is ordered by the hardware, loads run D rows
-//     ahead of the row being consumed, and the vector-memory counter is hand-counted -- every step issues exactly one
-//     store and one load, so "row r has landed" is the constant s_waitcnt vmcnt(2 (D - 1)) (stores of rows that do
-//     not exist go through an empty buffer descriptor and are dropped by its range check; the compiler cannot see
-//     the dependence between an LDS-DMA and a later ds_read);
+//     ahead of the row being consumed, and the vector-memory counter is hand-counted: "row r has landed" is
+//     s_waitcnt vmcnt(D - 1) -- only the D - 1 younger LOADS may be outstanding (the compiler cannot see the
+//     dependence between an LDS-DMA and a later ds_read; stores of rows that do not exist go through an empty buffer
+//     descriptor, so the instruction stream has no branches);
 //   * recomputed halo: 12 input rows and 6 intermediate rows per CHUNK of several hundred rows instead of per
 //     34-row tile; the 12 shared columns of neighbouring strips are read by neighbouring waves of one workgroup at
 //     about the same time (optionally kept in step by one s_barrier per 7 rows) and hit in L1 / L2.
@@ -135,15 +135,9 @@ __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel
 #pragma unroll
     for (int l = 0; l < K - 1; ++l) *reinterpret_cast<d2 *>(B + l * kBRow + 2 * lane) = (d2){0.0, 0.0};
 
-    // vector-memory stream: L(0), then per step exactly { store, L(r + D) }: D - 1 dummy { store, load } pairs up front
-    // make "younger than L(r)" the same 2 (D - 1) operations at every step
-    const __amdgpu_buffer_rsrc_t nowhere = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, 0, 0x00020000);
-    issue(0, 0);
+    // vector-memory stream: rows 0 .. D - 1 up front, then per step { one store, the load of row r + D }
 #pragma unroll
-    for (int k = 1; k < D; ++k) {
-        __builtin_amdgcn_raw_buffer_store_b128((u32x4){0u, 0u, 0u, 0u}, nowhere, 0, 0, 0);
-        issue(k, k);
-    }
+    for (int k = 0; k < D; ++k) issue(k, k);
 
     const double *const winA = A + 2 * lane;
     const double *const winB = B + 2 * lane;
@@ -151,7 +145,12 @@ __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel
     // sl = ring slot of input row r (= phase when NS == 7)
     auto step = [&](const int r, const int sl, auto phase_tag) {
         constexpr int P = decltype(phase_tag)::value;  // r mod 7
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+        // "input row r has landed": at most the D - 1 younger loads may be outstanding.  (Loads complete in order among
+        // themselves.  Counting the interleaved stores as well -- vmcnt(2 (D - 1)) -- assumes a younger store never
+        // completes before an older LDS-DMA load; the same assumption in kernels_3d_bf16_mfma.hip gave a wrong plane
+        // about once in 400 runs.  With D >= 3 this wait does not stall on store acknowledgements: the loads of the
+        // rows in between landed long ago, so the store of the previous step may still be in flight.)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1) : "memory");
         if (SYNC == 2) __builtin_amdgcn_s_barrier();
         auto wrap = [](int x) { return x >= NS ? x - NS : x; };
         // ---- levels K .. 2: the level-(l-1) row completed in the previous step, from its row buffer ----

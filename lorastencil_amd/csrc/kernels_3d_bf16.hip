@@ -265,8 +265,11 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 4 : 3)) void stencil3d_bf16_kernel
 #pragma unroll
                         for (int h = 0; h < CPL / 4; ++h) {  // 8 bytes (4 columns) per store
                             u32x2 v;
-                            v.x = pack_bf16(acc[s][r][2 * h].x, acc[s][r][2 * h].y);
-                            v.y = pack_bf16(acc[s][r][2 * h + 1].x, acc[s][r][2 * h + 1].y);
+                            // W.w[9]: 1 (exact) unless the plan asks for the matrix-pipe variant's contract
+                            // (normalised factors, one scaling of the sum: kernels_3d_bf16_mfma.hip)
+                            const float sc = TAPSET == TAPS3D_SEP ? W.w[9] : 1.0f;
+                            v.x = pack_bf16(acc[s][r][2 * h].x * sc, acc[s][r][2 * h].y * sc);
+                            v.y = pack_bf16(acc[s][r][2 * h + 1].x * sc, acc[s][r][2 * h + 1].y * sc);
                             *reinterpret_cast<u32x2 *>(dst + (long) r * a.ld + 4 * h) = v;
                         }
                     }
@@ -415,8 +418,9 @@ __global__ __launch_bounds__(256, 4) void stencil3d_bf16_ring_kernel(const Args3
 #pragma unroll
             for (int r = 0; r < RY; ++r) {
                 u32x2 v;
-                v.x = pack_bf16(acc[s][r][0].x, acc[s][r][0].y);
-                v.y = pack_bf16(acc[s][r][1].x, acc[s][r][1].y);
+                const float sc = TAPSET == TAPS3D_SEP ? W.w[9] : 1.0f;
+                v.x = pack_bf16(acc[s][r][0].x * sc, acc[s][r][0].y * sc);
+                v.y = pack_bf16(acc[s][r][1].x * sc, acc[s][r][1].y * sc);
                 __builtin_amdgcn_raw_buffer_store_b64(v, dst, store_off[r], 0, 0);
             }
             if constexpr (TAPSET != TAPS3D_SEP) {
@@ -460,8 +464,16 @@ hipError_t launch_bf16(const Plan &p, const void *in, void *out, int begin, int 
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
     Taps27f w;
     for (int k = 0; k < 27; ++k) w.w[k] = (float) p.w[k];
-    if (TAPSET == TAPS3D_SEP)
+    if (TAPSET == TAPS3D_SEP) {
         for (int k = 0; k < 9; ++k) w.w[k] = p.sep[k];
+        w.w[9] = 1.0f;
+        if (p.variant == LORA_VARIANT_MFMA && p.mfma3_valid) {
+            // single sweeps of a plan that runs the matrix-pipe variant (odd tails) follow ITS contract: the sum with
+            // the normalised factors (exact in the regime that contract is stated for), scaled once
+            for (int k = 0; k < 9; ++k) w.w[k] = p.mfma3_abc[k];
+            w.w[9] = p.mfma3_scale;
+        }
+    }
     if (a.plane * 2 >= (1L << 32)) return hipErrorInvalidValue;  // per-plane buffer descriptors: 32-bit offsets
     if (CPL == 4 && p.lds_dma)
         hipLaunchKernelGGL((stencil3d_bf16_ring_kernel<TAPSET, RY>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w);

@@ -269,6 +269,28 @@ int separable_27(const float *w, float *cba) {
     return 1;
 }
 
+// Factors for the bf16 MFMA variant (kernels_3d_bf16_mfma.hip): separable taps as scale * a' (x) b' (x) c' with the
+// normalised factors (divided by their first entry) EXACT in bf16, so that they can be matrix-instruction operands.
+int mfma_factors_27(const float *cba, float *scale, float *cba_n) {
+    auto bf16_exact = [](float x) {
+        uint32_t u;
+        std::memcpy(&u, &x, 4);
+        return std::isfinite(x) && (u & 0xffffu) == 0;
+    };
+    for (int f = 0; f < 3; ++f) {
+        const float first = cba[3 * f];
+        if (!(first != 0.0f) || !std::isfinite(first)) return 0;
+        for (int i = 0; i < 3; ++i) {
+            const float q = cba[3 * f + i] / first;
+            if (!bf16_exact(q) || !(q * first == cba[3 * f + i])) return 0;
+            cba_n[3 * f + i] = q;
+        }
+    }
+    const float ab = cba[6] * cba[3];  // a[0] b[0]
+    *scale = ab * cba[0];
+    return std::isfinite(*scale) && *scale != 0.0f;
+}
+
 int effective_weights(int shape, const double *params, double *w) {
     switch (shape) {
         case LORA_1D1R:

@@ -473,6 +473,55 @@ void oracle_step_3d_bf16_sep(const uint16_t *in, uint16_t *out, const float *c, 
     }
 }
 
+/* Contract of the engine's bf16 MATRIX-PIPE variant (kernels_3d_bf16_mfma.hip; no reference counterpart, unpinned):
+ * taps = scale * a' (x) b' (x) c' with the normalised factors (each divided by its first entry) exact in bf16;
+ *   S   = the 27-term sum  a'[dz] b'[dy] c'[dx] x  -- the matrix instruction accumulates it in fp32, which is EXACT
+ *         while the addends of a point span fewer than ~14 binary orders of magnitude; restated here as the exact sum
+ *         (double: 27 products of 8-bit by <= 8-bit significands) rounded once to fp32
+ *   out = bf16( fl32( scale * S ) ),  one round-to-nearest-even to bf16 per sweep. */
+int oracle_mfma_factors(const float *c, const float *b, const float *a, float *scale, float *cn, float *bn, float *an) {
+    const float *f[3] = {c, b, a};
+    float *o[3] = {cn, bn, an};
+    for (int k = 0; k < 3; k++) {
+        const float first = f[k][0];
+        if (!(first != 0.0f) || !isfinite(first)) return 0;
+        for (int i = 0; i < 3; i++) {
+            const float q = f[k][i] / first;
+            uint32_t u;
+            memcpy(&u, &q, 4);
+            if (!isfinite(q) || (u & 0xffffu) != 0 || !(q * first == f[k][i])) return 0;
+            o[k][i] = q;
+        }
+    }
+    const float ab = a[0] * b[0];
+    *scale = ab * c[0];
+    return isfinite(*scale) && *scale != 0.0f;
+}
+
+void oracle_step_3d_bf16_mfma(const uint16_t *in, uint16_t *out, float scale, const float *c, const float *b,
+                              const float *a, int heights, int rows, int cols, int threads) {
+    const int nt = pick_threads(threads);
+    (void) nt;
+    const ptrdiff_t plane = (ptrdiff_t) rows * cols;
+#pragma omp parallel for num_threads(nt) schedule(static) collapse(2) if (nt > 1)
+    for (int h = 1; h < heights - 1; h++) {
+        for (int row = 2; row < rows - 2; row++) {
+            for (int col = 4; col < cols - 4; col++) {
+                double S = 0.0;
+                for (int dz = 0; dz < 3; dz++)
+                    for (int dy = 0; dy < 3; dy++)
+                        for (int dx = 0; dx < 3; dx++) {
+                            const uint16_t *x = in + (h + dz - 1) * plane + (ptrdiff_t) (row + dy - 1) * cols + col + dx - 1;
+                            S += (double) a[dz] * (double) b[dy] * (double) c[dx] * (double) oracle_bf16_to_f32(*x);
+                        }
+                const float s32 = (float) S;
+                const float o = scale * s32;
+                out[h * plane + (ptrdiff_t) row * cols + col] = oracle_f32_to_bf16(o);
+            }
+        }
+    }
+}
+
 int oracle_run_bf16(int shape, const uint16_t *in, uint16_t *out, const double *w27, int times, const int *dims,
                     int threads) {
     return oracle_run_bf16_mode(shape, in, out, w27, times, dims, threads, 0);
@@ -496,8 +545,17 @@ int oracle_run_bf16_mode(int shape, const uint16_t *in, uint16_t *out, const dou
     memcpy(buf[0], in, count * sizeof(uint16_t));
     float c[3], b[3], a[3];
     const int sep = separable && oracle_separable_27(w, c, b, a);
+    float scale = 0.0f, cn[3], bn[3], an[3];
+    if (separable == 2 && !(sep && oracle_mfma_factors(c, b, a, &scale, cn, bn, an))) {
+        free(buf[0]);
+        free(buf[1]);
+        return -1;  /* these taps have no matrix-pipe form */
+    }
     for (int i = 0; i < times; i++) {
-        if (sep)
+        if (separable == 2)
+            oracle_step_3d_bf16_mfma(buf[i % 2], buf[(i + 1) % 2], scale, cn, bn, an, dims[0] + 2, dims[1] + 4, dims[2] + 8,
+                                     threads);
+        else if (sep)
             oracle_step_3d_bf16_sep(buf[i % 2], buf[(i + 1) % 2], c, b, a, dims[0] + 2, dims[1] + 4, dims[2] + 8, threads);
         else
             oracle_step_3d_bf16(buf[i % 2], buf[(i + 1) % 2], w, dims[0] + 2, dims[1] + 4, dims[2] + 8, threads);

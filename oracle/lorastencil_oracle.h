@@ -117,6 +117,11 @@ int oracle_run_bf16(int shape, const uint16_t *in, uint16_t *out, const double *
 int oracle_separable_27(const float *w27, float *c, float *b, float *a);
 void oracle_step_3d_bf16_sep(const uint16_t *in, uint16_t *out, const float *c, const float *b, const float *a,
                              int heights, int rows, int cols, int threads);
+/* separable == 2: the contract of the engine's matrix-pipe variant (oracle_step_3d_bf16_mfma in the .c file):
+ * exact 27-term sum with bf16-exact normalised factors, rounded to fp32, scaled once, rounded to bf16. */
+void oracle_step_3d_bf16_mfma(const uint16_t *in, uint16_t *out, float scale, const float *c, const float *b,
+                              const float *a, int heights, int rows, int cols, int threads);
+int oracle_mfma_factors(const float *c, const float *b, const float *a, float *scale, float *cn, float *bn, float *an);
 int oracle_run_bf16_mode(int shape, const uint16_t *in, uint16_t *out, const double *w27, int times, const int *dims,
                          int threads, int separable);
 

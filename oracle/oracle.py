@@ -245,9 +245,10 @@ def separable_27(weights):
     return (c, b, a) if ok else None
 
 
-def run_bf16(shape, a_bits: np.ndarray, times: int, weights=None, threads: int = 1, separable: bool = True) -> np.ndarray:
+def run_bf16(shape, a_bits: np.ndarray, times: int, weights=None, threads: int = 1, separable=True) -> np.ndarray:
     """The 3D operator on bf16 bit patterns with the reference's driver semantics.  ``separable`` (the engine's
-    default) evaluates exactly separable taps as x/y/z passes; False is the 27-tap order."""
+    default) evaluates exactly separable taps as x/y/z passes; False is the 27-tap order; "mfma" is the contract of the
+    engine's matrix-pipe variant (exact 27-term sum, one fp32 rounding, one scaling, one bf16 rounding)."""
     sid = shape_id(shape)
     a_bits = np.ascontiguousarray(a_bits, dtype=np.uint16)
     w = effective_weights(sid) if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
@@ -256,7 +257,7 @@ def run_bf16(shape, a_bits: np.ndarray, times: int, weights=None, threads: int =
     out = np.zeros_like(a_bits)
     u16 = ctypes.POINTER(ctypes.c_uint16)
     rc = lib().oracle_run_bf16_mode(sid, a_bits.ctypes.data_as(u16), out.ctypes.data_as(u16), _p(w), times, dims,
-                                    threads, 1 if separable else 0)
+                                    threads, 2 if separable == "mfma" else (1 if separable else 0))
     if rc != 0:
         raise ValueError("oracle_run_bf16_mode failed")
     return out

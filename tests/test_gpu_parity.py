@@ -636,6 +636,57 @@ def test_bf16_fused_two_step_launches_equal_step_by_step(L, O, shape, dims):
     assert np.array_equal(dst.view(torch.int16).cpu().numpy().view(np.uint16), exp)
 
 
+@pytest.mark.parametrize("dims", [(8, 28, 64), (9, 31, 248), (5, 3, 8), (37, 64, 360), (40, 61, 128)])
+def test_bf16_matrix_pipe_variant_matches_its_contract(L, O, dims):
+    """LORA_VARIANT_MFMA of a bf16 box plan (kernels_3d_bf16_mfma.hip: v_mfma_f32_16x16x32_bf16, two applications per
+    launch) against the oracle's restatement of ITS contract (exact 27-term sum -> fp32 -> one scaling -> bf16):
+    bit for bit in the exact regime (small integers, normalised taps, one pair of fused launches), within one bf16 ulp
+    on gaussian data and over longer runs (tails are single sweeps under the same contract)."""
+    import torch
+
+    shape = "box3d1r"
+    w0 = O.effective_weights(shape)
+    rng = np.random.default_rng(3)
+    for wname, w in (("ref", w0), ("norm", w0 / w0.sum())):
+        for dname in ("int", "gauss"):
+            ps = O.padded_shape(shape, dims)
+            a = rng.integers(0, 100, ps).astype(np.float64) if dname == "int" else rng.standard_normal(ps)
+            bits = O.to_bf16(a)
+            plan = L.Plan(shape, dims, dtype="bf16").set_weights(w)
+            plan.set_variant(L.VARIANT_MFMA)
+            assert plan.kernel_name == "stencil3d_bf16_mfma2_kernel" and plan.get_option("variant") == L.VARIANT_MFMA
+            if dname == "int":
+                # ONE fused launch on small integers: every partial sum of both levels is exact in fp32 and the hi + lo
+                # split loses nothing -> the contract bit for bit (two sweeps of the oracle, level-1 halo = 0)
+                src = torch.from_numpy(bits.view(np.int16)).cuda()
+                dst = src.clone()
+                plan.step2(src, dst)
+                torch.cuda.synchronize()
+                assert np.array_equal(dst.cpu().numpy().view(np.uint16),
+                                      O.run_bf16(shape, bits, 2, weights=w, separable="mfma")), (dims, wname)
+            for times in (4, 5, 9):
+                if wname == "ref" and times > 4:
+                    continue  # x 36 per sweep: out of the bf16 range soon
+                b0 = torch.from_numpy(bits.view(np.int16)).cuda()
+                b1 = torch.zeros_like(b0)
+                plan.run(b0, b1, times)
+                torch.cuda.synchronize()
+                got = (b0, b1)[times % 2].cpu().numpy().view(np.uint16)
+                exp = O.run_bf16(shape, bits, times, weights=w, separable="mfma")
+                g, e = O.from_bf16(got), O.from_bf16(exp)
+                assert np.abs(g - e).max() <= 2.0 ** -7 * np.abs(e).max(), (dims, wname, dname, times)
+                assert (got != exp).mean() < 0.02  # and nearly everywhere identical
+    # the variant exists for box taps with bf16-exact normalised factors only
+    with pytest.raises(L.LoraError):
+        L.Plan("star3d1r", (8, 16, 64), dtype="bf16").set_variant(L.VARIANT_MFMA)
+    with pytest.raises(L.LoraError):
+        L.Plan(shape, (8, 16, 64), dtype="bf16").set_weights(rng.standard_normal(27)).set_variant(L.VARIANT_MFMA)
+    with pytest.raises(L.LoraError):
+        L.Plan(shape, (8, 16, 64)).set_variant(L.VARIANT_MFMA)  # fp64 3D: no matrix-pipe form
+    # and the default stays the vector kernel (measured faster: DESIGN.md section 3.4c)
+    assert L.Plan(shape, (8, 16, 64), dtype="bf16").kernel_name == "stencil3d_bf16_fused2_kernel"
+
+
 def test_bf16_host_operator_and_random_taps(L, O):
     rng = np.random.default_rng(11)
     shape, dims = "box3d1r", (6, 10, 64)

@@ -176,3 +176,23 @@ def test_baseline_config0_1d1r_2pow20_100_steps_cpu_path():
     exp = ref.run_chain(a, p, t)
     got = o.run("1d1r", a, t, threads=o.max_threads())
     assert np.isfinite(exp).all() and np.array_equal(got[:-1], exp[:-1])
+
+
+def test_bf16_matrix_pipe_contract_is_the_correctly_rounded_sum():
+    """oracle_step_3d_bf16_mfma (the contract of the engine's bf16 MFMA variant): on small integers it equals the
+    separable fp32 order exactly (every partial sum is exact); on gaussian data the two contracts differ by at most one
+    bf16 ulp and agree nearly everywhere -- both are roundings of the same 27-point sum."""
+    from oracle import oracle as O
+
+    rng = np.random.default_rng(1)
+    shape, dims = "box3d1r", (6, 10, 24)
+    w = O.effective_weights(shape)
+    bits = O.to_bf16(rng.integers(0, 100, O.padded_shape(shape, dims)).astype(np.float64))
+    assert np.array_equal(O.run_bf16(shape, bits, 2, weights=w, separable="mfma"), O.run_bf16(shape, bits, 2, weights=w))
+    g = O.to_bf16(rng.standard_normal(O.padded_shape(shape, dims)))
+    wn = w / w.sum()
+    a, b = O.run_bf16(shape, g, 3, weights=wn, separable="mfma"), O.run_bf16(shape, g, 3, weights=wn)
+    fa, fb = O.from_bf16(a), O.from_bf16(b)
+    assert np.abs(fa - fb).max() <= 2.0 ** -7 * np.abs(fb).max() and (a != b).mean() < 0.2
+    with pytest.raises(ValueError):
+        O.run_bf16(shape, g, 1, weights=rng.standard_normal(27), separable="mfma")  # no bf16-exact factors

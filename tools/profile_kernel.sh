@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/pk_${ta
 grep '^{' $ROOT/gpurun_out/pk_${tag}_stats.log | tail -3 | cut -c1-300
 pass() {
     name=$1; shift
-    case " ${PK_PASSES:-fetch write sq1 sq2 tcc vm tcp wr rd ea} " in *" $name "*) ;; *) return 0;; esac
+    case " ${PK_PASSES:-fetch write sq1 sq2 tcc vm tcp wr rd ea mfma} " in *" $name "*) ;; *) return 0;; esac
     rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $ROOT/gpurun_out/pk_${tag}_$name -- python3 $ROOT/$script "${ARGS[@]}" > $ROOT/gpurun_out/pk_${tag}_$name.log 2>&1 || echo "pass $name failed"
     echo "pass $name done"
 }
@@ -27,4 +27,5 @@ pass tcp TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_
 pass wr TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_TAG_STALL_sum
 pass rd TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum
 pass ea TCC_REQ_sum TCC_READ_sum TCC_WRITE_sum TCC_TOO_MANY_EA_WRREQS_STALL_sum
+pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_BF16 SQ_INSTS_MFMA SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 cd $ROOT
