@@ -172,7 +172,12 @@ void plan_refresh(Plan &p) {
             p.variant = LORA_VARIANT_DIRECT;
             p.lowrank_valid = false;
         }
-        if (p.variant == LORA_VARIANT_MFMA || p.generic)
+        // odd innermost extent (rows only 8-byte aligned): the tiled kernels do not apply, but the row-streaming kernel
+        // does -- its 16-byte row pieces need dword alignment only, and the last, half-valid column pair of a row is
+        // cut by the store descriptor's per-dword range check -- so fused launches keep their speed and only the
+        // single-sweep tail (at most one launch per run) goes through the generic kernel
+        const bool odd_stream = p.generic && p.stream2 && p.boundary == LORA_BC_REFERENCE;
+        if (p.variant == LORA_VARIANT_MFMA || (p.generic && !odd_stream))
             p.steps_per_launch = 1;
         else
             p.steps_per_launch = p.steps_per_launch_req == 0 ? 4 : p.steps_per_launch_req;
@@ -258,7 +263,7 @@ void plan_refresh(Plan &p) {
                 }
             }
         }
-        p.kernel_name = p.generic ? kernel_name_generic(p)
+        p.kernel_name = (p.generic && p.steps_per_launch == 1) ? kernel_name_generic(p)
                         : (p.variant == LORA_VARIANT_MFMA)
                             ? kernel_name_2d_mfma(p)
                             : (p.steps_per_launch >= 2 ? (p.stream2 ? kernel_name_2d_stream(p) : kernel_name_2d_fused2(p))
@@ -571,7 +576,7 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         p.fused_rows_req = value;
     } else if (!std::strcmp(key, "steps_per_launch")) {
         if (value < 0 || value > 8 || (value & (value - 1))) return LORA_EINVAL;  // 0 (auto), 1, 2, 4, 8
-        const bool fusable = (p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && !p.generic) ||
+        const bool fusable = (p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && (!p.generic || p.stream2)) ||
                              (p.ndim == 3 && !p.generic) || p.ndim == 1;
         if (value >= 2 && !fusable) return LORA_EUNSUPPORTED;
         if (value > 2 && p.ndim == 3) return LORA_EUNSUPPORTED;  // 3D kernels fuse two applications
@@ -695,7 +700,8 @@ int lora_plan_step(lora_plan *plan, const void *d_in, void *d_out, void *stream)
 int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream) {
     if (!plan) return LORA_EINVAL;
     Plan &p = plan->p;
-    const bool ok2 = p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && !p.generic;
+    const bool ok2 = p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT &&
+                     (!p.generic || (p.stream2 && p.boundary == LORA_BC_REFERENCE));
     const bool ok3 = p.ndim == 3 && !p.generic;
     if (!ok2 && !ok3) return LORA_EUNSUPPORTED;
     if (int rc = lora::check_buffers(d_in, d_out)) return rc;
@@ -830,7 +836,7 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
     }
     int done = 0;
     const int K = p.steps_per_launch;  // applications per fused launch: 2 (2D, 3D) or 2 / 4 / 8 (1D)
-    const bool can_fuse = K >= 2 && !p.generic &&
+    const bool can_fuse = K >= 2 && (!p.generic || (p.ndim == 2 && p.stream2 && p.boundary == LORA_BC_REFERENCE)) &&
                           ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) || p.ndim == 3 || p.ndim == 1);
     if (can_fuse && (times >= 2 * K || (p.ndim == 2 && K == 4 && times >= 4))) {
         // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes the other one,

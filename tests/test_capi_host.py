@@ -175,7 +175,9 @@ def test_shape_tables(L):
 
 
 def test_plan_validation(L):
-    assert L.Plan("star2d1r", (64, 127)).kernel_name == "stencil2d_generic_kernel"  # odd extent: generic fallback
+    # odd innermost extent: the row-streaming kernel for fused launches, the generic fallback for single sweeps / 3D
+    assert L.Plan("star2d1r", (64, 127)).kernel_name == "stencil2d_stream_kernel"
+    assert L.Plan("star2d1r", (64, 127)).set_option("steps_per_launch", 1).kernel_name == "stencil2d_generic_kernel"
     assert L.Plan("box3d1r", (4, 4, 5)).kernel_name == "stencil3d_generic_kernel"
     with pytest.raises(L.LoraError):
         L.Plan("star2d1r", (0, 128))
