@@ -183,6 +183,8 @@ int lora_set_default_normalize(int on);
  *                     order; the oracle restates both orders, see lora_separable_3x3x3)
  *   cols_per_lane, lds_dma, fused_pipeline                              bf16 kernel variants
  *   graph             -1 auto / 0 / 1 : hipGraph replay of lora_plan_run
+ *   scratch           -1 auto (= 1) / 0 / 1 : lora_plan_run may allocate one more grid (see there)
+ *   mfma_split        bf16 matrix-pipe variant: 1 = hi + lo split of the intermediate (its contract), 0 = one bf16 rounding
  *   stream            2D fused launches: 1 = row-streaming kernel (wave-autonomous column strips, kernels_2d_stream.hip),
  *                     0 = tile kernel; stream_rows (output rows per chunk, 0 = auto), stream_depth (2..6 input rows in
  *                     flight per wave), stream_sync (one barrier per 7 rows keeps a workgroup's strips in step)
@@ -226,8 +228,12 @@ int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int b
 enum lora_halo_mode { LORA_HALO_COPY = 0, LORA_HALO_ZERO = 1, LORA_HALO_WRAP = 2 };
 int lora_plan_halo(lora_plan *plan, void *d_dst, const void *d_src, int mode, void *stream);
 /* The time-step driver (2d/gpu.cu:544-546): `times` applications ping-ponging between the two
- * buffers starting from d_buf0; the result is in buffer [times % 2].  The caller must have put
- * the padded input in d_buf0 and zeros in d_buf1 to get the reference semantics. */
+ * buffers starting from d_buf0; the result is in buffer [times % 2] (the other buffer's interior is
+ * unspecified).  The caller must have put the padded input in d_buf0 and zeros in d_buf1 to get the
+ * reference semantics.  Fused launches move K time levels per buffer flip, so an ODD number of them
+ * would leave the data in the wrong buffer: the plan then routes the last two through a scratch grid of
+ * its own (one more padded array, allocated on first need, freed with the plan; option "scratch" = 0
+ * trades it for a shorter launch schedule instead). */
 int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream);
 /* lora_plan_run with HIP events recorded on `stream` around its two kinds of launches -- the fused multi-application
  * launches and the single-sweep tail -- so that a caller can quote the average duration of the dominant kernel over

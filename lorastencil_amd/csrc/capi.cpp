@@ -454,6 +454,7 @@ int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, con
 
 void lora_plan_destroy(lora_plan *plan) {
     if (plan && plan->graph_exec) (void) hipGraphExecDestroy(plan->graph_exec);
+    if (plan && plan->scratch) (void) hipFree(plan->scratch);
     delete plan;
 }
 
@@ -547,6 +548,9 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "stream_sync")) {
         if (value < 0 || value > 2) return LORA_EINVAL;
         p.stream_sync = value;
+    } else if (!std::strcmp(key, "scratch")) {
+        if (value < -1 || value > 1) return LORA_EINVAL;
+        p.use_scratch = value;
     } else if (!std::strcmp(key, "mfma_split")) {
         p.mfma_split = value ? 1 : 0;
     } else if (!std::strcmp(key, "graph")) {
@@ -782,6 +786,58 @@ int lora_plan_stepk(lora_plan *plan, const void *d_in, void *d_out, void *stream
 }
 
 // The launches of one run, in order, on `stream` (also what gets captured into a hipGraph).
+// How a run of `times` steps is cut into launches: nk launches of the plan's K applications, n2 two-application launches
+// (2D with K = 4 only), the rest single sweeps.  The fused launches must leave the data in buffer 0.
+struct FusedSchedule {
+    int nk = 0, n2 = 0;
+    bool scratch = false;  // odd number of fused launches: the last two hops go through the plan's scratch grid
+};
+
+static bool ensure_scratch(lora_plan *plan) {
+    const size_t bytes = lora_plan_padded_bytes(plan);
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    if (plan->scratch && plan->scratch_bytes == bytes && plan->scratch_device == dev) return true;
+    if (plan->scratch) (void) hipFree(plan->scratch);
+    plan->scratch = nullptr;
+    if (hipMalloc(&plan->scratch, bytes) != hipSuccess) {
+        (void) hipGetLastError();
+        plan->scratch = nullptr;
+        return false;
+    }
+    // cells the kernels never write (pads beyond the halo ring do not exist; the ring itself is copied per run)
+    if (hipMemset(plan->scratch, 0, bytes) != hipSuccess) (void) hipGetLastError();
+    plan->scratch_bytes = bytes;
+    plan->scratch_device = dev;
+    return true;
+}
+
+static FusedSchedule fused_schedule(lora_plan *plan, int times, bool can_fuse, bool allocate = true) {
+    const Plan &p = plan->p;
+    FusedSchedule fs;
+    const int K = p.steps_per_launch;
+    if (!can_fuse || K < 2) return fs;
+    const bool four = p.ndim == 2 && K == 4;
+    fs.nk = times / K;
+    fs.n2 = four ? (times - K * fs.nk) / 2 : 0;
+    const int n = fs.nk + fs.n2;
+    if (n % 2 == 0) return fs;
+    if (n >= 3 && p.use_scratch != 0 && (!allocate || ensure_scratch(plan))) {
+        fs.scratch = true;
+        return fs;
+    }
+    // no scratch grid: an even number of launches instead
+    if (four && fs.nk >= 1) {
+        fs.nk -= 1;
+        fs.n2 += 2;
+    } else if (four) {
+        fs.n2 -= 1;
+    } else {
+        fs.nk -= 1;
+    }
+    return fs;
+}
+
 struct RunMarks {  // lora_plan_run_profiled: events around the fused and the single-sweep segment
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start | K-launches | 2-launches | singles
     int fused_launches = 0, two_launches = 0, single_launches = 0;
@@ -838,39 +894,40 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
     const int K = p.steps_per_launch;  // applications per fused launch: 2 (2D, 3D) or 2 / 4 / 8 (1D)
     const bool can_fuse = K >= 2 && (!p.generic || (p.ndim == 2 && p.stream2 && p.boundary == LORA_BC_REFERENCE)) &&
                           ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) || p.ndim == 3 || p.ndim == 1);
-    if (can_fuse && (times >= 2 * K || (p.ndim == 2 && K == 4 && times >= 4))) {
-        // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes the other one,
-        // so while fused launches run BOTH physical buffers carry buffer 0's halo; an even number of them leaves
-        // the data in buffer 0, after which (reference boundary) buffer 1's halo is put back to 0 and the remaining
-        // 0..3 steps are single sweeps -- the result and its halo end up exactly where the step-by-step driver
-        // leaves them.  With the Dirichlet boundary both halos simply stay.
+    FusedSchedule fs = fused_schedule(plan, times, can_fuse);
+    if (fs.nk + fs.n2 > 0) {
+        // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes another one, so
+        // while fused launches run every physical buffer carries buffer 0's halo; the data must end in buffer 0, after
+        // which (reference boundary) buffer 1's halo is put back to 0 and the remaining steps are single sweeps -- the
+        // result and its halo end up exactly where the step-by-step driver leaves them.  An EVEN number of launches
+        // ping-pongs there by itself; an odd number (>= 3) makes its last two hops through a scratch grid owned by the
+        // plan (.. -> buffer 1 -> scratch -> buffer 0), which costs memory -- one more grid of 288 GB -- instead of a
+        // four-sweep launch replaced by two two-sweep ones (star2d1r 16384^2, 20 sweeps: 6.2 -> 5.5 ms).  With the
+        // Dirichlet boundary all halos simply stay.
         if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
-        int pairs = (times / K) & ~1;
-        int twos = 0;  // 2D, K = 4: two-application launches take the tail, so that at most one single sweep remains
-        if (p.ndim == 2 && K == 4) {
-            pairs = times / 4;
-            twos = (times - 4 * pairs) / 2;
-            if ((pairs + twos) & 1) {  // the data must end up in buffer 0: an even number of fused launches
-                pairs -= 1;
-                twos += 2;
-            }
-        }
+        const int n = fs.nk + fs.n2;
+        void *scratch = fs.scratch ? plan->scratch : nullptr;
         if (!dirichlet)
             if (int rc = halo(buf[1], buf[0], lora::HALO_COPY, "halo copy")) return rc;
-        for (int k = 0; k < pairs; ++k) {
-            const int rc = lora_plan_stepk(plan, buf[k % 2], buf[(k + 1) % 2], stream);
+        if (scratch)
+            if (int rc = halo(scratch, buf[0], lora::HALO_COPY, "halo copy")) return rc;
+        for (int k = 0; k < n; ++k) {
+            void *src = buf[k % 2], *dst = buf[(k + 1) % 2];
+            if (scratch && k == n - 2) dst = scratch;  // k odd: buffer 1 -> scratch
+            if (scratch && k == n - 1) {               // k even: scratch -> buffer 0
+                src = scratch;
+                dst = buf[0];
+            }
+            if (k == fs.nk) mark(1);
+            const int rc = k < fs.nk ? lora_plan_stepk(plan, src, dst, stream) : lora_plan_step2(plan, src, dst, stream);
             if (rc != LORA_OK) return rc;
         }
-        mark(1);
-        for (int k = pairs; k < pairs + twos; ++k) {
-            const int rc = lora_plan_step2(plan, buf[k % 2], buf[(k + 1) % 2], stream);
-            if (rc != LORA_OK) return rc;
-        }
+        if (fs.n2 == 0) mark(1);
         if (!dirichlet)
             if (int rc = halo(buf[1], nullptr, lora::HALO_ZERO, "halo reset")) return rc;
-        done = K * pairs + 2 * twos;
-        if (marks) marks->fused_launches = pairs;
-        if (marks) marks->two_launches = twos;
+        done = K * fs.nk + 2 * fs.n2;
+        if (marks) marks->fused_launches = fs.nk;
+        if (marks) marks->two_launches = fs.n2;
     } else {
         mark(1);
     }
@@ -915,6 +972,7 @@ int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *
           plan->graph_times == times && plan->graph_epoch == p.epoch)) {
         drop_graph(plan);
         if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
+        (void) fused_schedule(plan, times, true);  // a scratch grid, if this run wants one, is allocated BEFORE capture
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) {

@@ -85,6 +85,7 @@ struct Plan {
     LowRank2D lowrank{};
     std::string kernel_name;
     int boundary = LORA_BC_REFERENCE;  // what halo cells hold between sweeps (lora_plan_set_boundary)
+    int use_scratch = -1; // odd numbers of fused launches route through a scratch grid owned by the plan: -1 / 1 yes, 0 no
     int use_graph = -1;   // -1 auto (small grids, many launches, non-default stream), 0 never, 1 whenever possible
     unsigned epoch = 0;   // bumped by every change of taps / options: invalidates a cached graph
 };
@@ -147,4 +148,8 @@ struct lora_plan {
     void *graph_buf[2] = {nullptr, nullptr};
     int graph_times = -1;
     unsigned graph_epoch = 0;  // value of p.epoch the graph was captured at
+    // one more padded grid, allocated on first need (lora_plan_run with an odd number of fused launches)
+    void *scratch = nullptr;
+    size_t scratch_bytes = 0;
+    int scratch_device = -1;
 };

@@ -50,7 +50,7 @@ constexpr int kSlot = kTR * kPitch;      // elements per plane tile (4 KB)
 constexpr int kDepth = 2;                // input planes in flight
 constexpr int kRing = kDepth + 1;        // ring slots (= the unroll factor of the plane loop)
 constexpr int kWaveLds = (kRing + 1) * kSlot;  // ring + the level-1 tile, in elements
-constexpr int kStoresPerStep = 8, kLoadsPerStep = 4;
+constexpr int kLoadsPerStep = 4;        // (and 8 stores per step)
 
 struct ArgsMfma3 {
     const u16 *in;

@@ -241,7 +241,7 @@ FUSED_2D = {"stream4": {}, "stream2": {"steps_per_launch": 2}, "tile2": {"stream
                                         ("star2d1r", (700, 118)), ("box2d3r", (13, 232)), ("star2d3r", (40, 2100))])
 def test_fused_two_step_launches_equal_step_by_step(L, O, shape, dims, kernel):
     a = O.reference_input(shape, dims)
-    for t in (4, 5, 6, 7, 8, 9, 10, 11):
+    for t in (4, 5, 6, 7, 8, 9, 10, 11, 12, 13):   # 12, 13: three four-sweep launches, the last two through the scratch grid
         got = plan_run(L, shape, a, t, options=FUSED_2D[kernel])
         exp = O.run(shape, a, t)
         # whole padded buffer: interior AND the halo state the step-by-step driver leaves behind
@@ -249,6 +249,25 @@ def test_fused_two_step_launches_equal_step_by_step(L, O, shape, dims, kernel):
             assert np.array_equal(got, exp), f"{shape} {dims} t={t}"
         else:
             assert rel_err(got, exp) < 1e-13, f"{shape} {dims} t={t}"
+
+
+@pytest.mark.parametrize("shape,dims,times", [("star2d1r", (150, 380), 20), ("box2d3r", (70, 130), 12), ("star3d1r", (20, 24, 64), 10),
+                                              ("box3d1r", (12, 16, 64), 6), ("1d1r", (20000,), 27)])
+def test_odd_numbers_of_fused_launches_with_and_without_the_scratch_grid(L, O, shape, dims, times):
+    """lora_plan_run with an odd number of fused launches: routed through the plan's scratch grid (default) or, with
+    option scratch = 0, rescheduled to an even number -- same result, whole padded buffer, as the step-by-step driver."""
+    w = O.effective_weights(shape)
+    w = w / w.sum()
+    a = O.reference_input(shape, dims)
+    exp = O.run(shape, a, times, weights=w)
+    for scratch in (1, 0):
+        got = plan_run(L, shape, a, times, weights=w, options={"scratch": scratch})
+        if a.ndim == 1:
+            got[-1] = exp[-1]
+        assert rel_err(got, exp) < 1e-13, (shape, scratch)
+        h = L.ops.halo(shape)
+        edge = tuple(slice(0, k) for k in h)
+        assert np.array_equal(got[edge], exp[edge])
 
 
 @pytest.mark.parametrize("shape,dims", [("star2d1r", (300, 700)), ("star2d1r", (1, 2)), ("star2d3r", (2100, 2600)),
