@@ -545,6 +545,10 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "stream_depth")) {
         if (value < 2 || value > 6) return LORA_EINVAL;
         p.stream_depth = value;
+    } else if (!std::strcmp(key, "stream_share")) {
+        p.stream_share = value ? 1 : 0;
+    } else if (!std::strcmp(key, "stream_prefetch")) {
+        p.stream_prefetch = value ? 1 : 0;
     } else if (!std::strcmp(key, "stream_sync")) {
         if (value < 0 || value > 2) return LORA_EINVAL;
         p.stream_sync = value;
@@ -667,8 +671,8 @@ const char *lora_plan_kernel_signature(const lora_plan *plan) {
     if (k == "stencil2d_stream_kernel") {
         const int K = p.steps_per_launch, w = lora::stream_strip_width(K);
         const int depth = p.boundary == LORA_BC_DIRICHLET ? 4 : (K == 4 ? (p.stream_depth == 2 ? 2 : 3) : p.stream_depth);
-        std::snprintf(buf, sizeof buf, "eval=%d,k=%d,depth=%d,sync=%d,rows=%d,bc=%d", p.fused_eval, K, depth,
-                      p.stream_sync, lora::stream_rows_per_chunk(p, K, p.dims[0], (p.dims[1] + w - 1) / w), p.boundary);
+        std::snprintf(buf, sizeof buf, "eval=%d,k=%d,depth=%d,sync=%d%s,rows=%d,bc=%d", p.fused_eval, K, depth,
+                      p.stream_sync, p.stream_share ? ",share=1" : ((K == 4 && p.stream_sync == 1 && p.stream_prefetch) ? ",pf=1" : ""), lora::stream_rows_per_chunk(p, K, p.dims[0], (p.dims[1] + w - 1) / w), p.boundary);
     }
     else if (k == "stencil2d_fused2_kernel")
         std::snprintf(buf, sizeof buf, "eval=%d,rows=%d,persist=%d,panel=%d,bc=%d", p.fused_eval, p.fused_rows,

@@ -70,6 +70,8 @@ struct Plan {
     int stream2 = 1;          // 2D fused: row-streaming kernel (kernels_2d_stream.hip, default) or the tile kernel (0)
     int stream_rows = 0;      // ... output rows per chunk (0 = auto: whole rounds of resident waves)
     int stream_depth = 4;     // ... input rows in flight per wave (2..6; at most 3 with four applications per launch)
+    int stream_share = 0;     // ... one ring of whole rows per workgroup, a barrier per row (fewer, aligned L2 requests)
+    int stream_prefetch = 0;  // ... K = 4: fetch the next level's LDS window while the current level computes (measured: no gain)
     int stream_sync = 1;      // ... s_barrier per 7 rows (1) / per row (2) keeps a workgroup's four strips in step
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
     int fused_pipeline = 0;   // 3D bf16 fused: 1 = level 2 one plane behind level 1, one barrier per plane (no gain measured)

@@ -65,6 +65,24 @@ struct ArgsStream {
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// One global -> LDS row piece with only the lanes of `mask` active (SHARE: a wave's quarter of the workgroup's row is
+// 56 or 62 pieces of 16 bytes).  Written as one asm block that narrows EXEC around the instruction: the same thing as
+// `if (lane < n) __builtin_amdgcn_global_load_lds(...)`, but that branch in every step made the register allocator
+// spill 370 VGPRs of the rotating accumulators.  LDS address = M0 + 16 x lane.
+__device__ __forceinline__ void dma_piece_masked(const double *gptr, unsigned lds_byte_addr, unsigned long long mask) {
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %0, exec\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %3, off\n\t"
+        "s_mov_b64 exec, %0"
+        : "=&s"(saved)
+        : "s"(mask), "s"(lds_byte_addr), "v"(gptr)
+        : "memory", "m0");
+}
+
 // Step r of a chunk whose first output row is i0 consumes input row i0 - 3 K + r and completes, for l = 1..K, the
 // level-l row  i0 - 3 K - 4 l + 1 + r  (level l lags 3 rows -- its radius -- plus one step of hand-off behind level
 // l - 1: a level's row is written to its LDS row buffer in one step and picked up by the next level in the following
@@ -78,41 +96,72 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 //
 // D = input rows in flight per wave; SYNC = 1: one s_barrier per 7 rows keeps the four strips of a workgroup in step
 // (L2 hits on their shared columns), 2: one per row (L1 hits).
-template <int EVAL, int K, int D, int SYNC, bool DIRI>
+//
+// SHARE: the four strips of a workgroup overlap by 6 K columns each and start at odd multiples of 8 bytes, so four private
+// 1 KiB row pieces ask L2 for 36 lines of 128 bytes where the workgroup's 440 (476) distinct columns are 28 (31) -- and
+// L2 -> L1 read requests are what bounds this kernel (64-86 in flight per CU whatever the occupancy).  In
+// this mode the workgroup keeps ONE ring of whole rows: its window starts on a 128-byte boundary (padded column
+// 4 OUTW g - 16), each wave fetches a quarter of it (112 / 124 columns), one s_barrier per row -- behind every wave's own
+// vmcnt wait -- publishes the row, and every wave reads its window (and the halo source row) out of the shared row.
+// The ring has one slot more than the slots a step touches (rows r, r - 7 or r - 3, r + D), because waves of one
+// workgroup can be one barrier apart.
+template <int EVAL, int K, int D, int SYNC, bool DIRI, bool PREFETCH, bool SHARE>
 __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel(const ArgsStream a, const Taps49 W, const LowRankTaps F) {
-    constexpr int NS = stream_slots(K);
+    constexpr int NS = SHARE ? (K == 2 ? 8 : 11) : stream_slots(K);
     constexpr int OUTW = stream_out_w(K);
-    constexpr int WLDS = stream_wave_lds(K);
+    constexpr int SHIFT = 20 - 3 * K;                     // SHARE: ring column of the first strip's window
+    constexpr int RW = SHARE ? (K == 2 ? 496 : 448) : kSInW;  // doubles per ring row (SHARE: the whole workgroup's)
+    constexpr int RINGW = SHARE ? NS * RW : 4 * NS * RW;  // doubles of all rings of the workgroup
     static_assert(K == 2 || K == 4, "applications per launch");
     static_assert(D >= 2 && D <= 6 && (K == 2 || D <= 3) && (!DIRI || (K == 2 && D <= 4)), "rows in flight");
+    static_assert(!SHARE || (SHIFT + 3 * OUTW + kSInW <= RW && RW % 8 == 0), "shared ring row");
     // K = 4: 4 x 13 KB + slack = 53,312 B -- three workgroups per CU need <= 53,760 B each (the 160 KB are handed out in
-    // 1,280-byte granules: at 54,016 B only two were resident, PMC occupancy 1.74 of 3 waves per SIMD)
-    __shared__ __attribute__((aligned(16))) double lds[4 * WLDS + kLdsSlack];
+    // 1,280-byte granules: at 54,016 B only two were resident, PMC occupancy 1.74 of 3 waves per SIMD).  SHARE: 51,776 B.
+    __shared__ __attribute__((aligned(128))) double lds[RINGW + 4 * (K - 1) * kBRow + kLdsSlack];
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *const A = lds + wv * WLDS;  // ring: slot s = input row (step) s mod NS
-    double *const B = A + NS * kSInW;   // B + (l - 1) kBRow: the level-l row handed to level l + 1
+    double *const A = SHARE ? lds : lds + wv * NS * RW;         // ring: slot s = input row (step) s mod NS
+    double *const B = lds + RINGW + wv * (K - 1) * kBRow;       // B + (l - 1) kBRow: the level-l row handed to level l + 1
 
     // wave -> (chunk, strip): consecutive waves take consecutive strips of one chunk; waves past the end of the
-    // launch (last workgroup only) run the same instruction stream on the last strip with every store switched off
-    const int total = a.strips * a.chunks;
-    const int wlin = xcd_contiguous(blockIdx.x, gridDim.x) * 4 + wv;
-    const bool spare = wlin >= total;
-    const int wl = spare ? total - 1 : wlin;
-    const int chunk = wl / a.strips, strip = wl - chunk * a.strips;
+    // launch (last workgroup only; SHARE: past the end of a row of strips) run the same instruction stream with every
+    // store switched off
+    int chunk, strip;
+    bool spare;
+    const int blk = xcd_contiguous(blockIdx.x, gridDim.x);
+    if (SHARE) {
+        const int groups_x = (a.strips + 3) / 4;
+        chunk = blk / groups_x;
+        strip = (blk - chunk * groups_x) * 4 + wv;
+        spare = strip >= a.strips;
+    } else {
+        const int total = a.strips * a.chunks;
+        const int wlin = blk * 4 + wv;
+        spare = wlin >= total;
+        const int wl = spare ? total - 1 : wlin;
+        chunk = wl / a.strips;
+        strip = wl - chunk * a.strips;
+    }
     const int i0 = a.row_begin + chunk * a.rows;  // first output row of the chunk (interior coordinates)
     const int j0 = strip * OUTW;                  // first output column of the strip
     const int row_hi = spare ? i0 : min(i0 + a.rows, a.row_end);
 
     // input: interior columns j0 - 3 K + 2 lane, +1 = padded columns j0 - 3 K + 4 + 2 lane (clamped into the padded
-    // array: clamped pieces only feed intermediate cells outside the interior, which are forced below)
-    const int gcol = min(max(j0 - 3 * K + 4 + 2 * lane, 0), a.n + 6);
+    // array: clamped pieces only feed intermediate cells outside the interior, which are forced below).  SHARE: this
+    // wave's quarter of the workgroup's row, padded columns 4 OUTW g - 16 + (RW / 4) wv + 2 lane, lanes < RW / 8.
+    const int gcol = SHARE ? min(max((strip - wv) * OUTW - 16 + (RW / 4) * wv + 2 * lane, 0), a.n + 6)
+                           : min(max(j0 - 3 * K + 4 + 2 * lane, 0), a.n + 6);
     const double *const in_lane = a.in + gcol;
     auto issue = [&](int r, int slot) {
         const int pr = min(max(i0 - 3 * K + 4 + r, 0), a.m + 7);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (in_lane + (size_t) pr * a.ld),
-                                         (__attribute__((address_space(3))) void *) (A + slot * kSInW), 16, 0, 0);
+        if constexpr (SHARE) {
+            const unsigned dst = (unsigned) (unsigned long) (__attribute__((address_space(3))) void *) (A + slot * RW + (RW / 4) * wv);
+            dma_piece_masked(in_lane + (size_t) pr * a.ld, dst, (1ull << (RW / 8)) - 1ull);
+        } else {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (in_lane + (size_t) pr * a.ld),
+                                             (__attribute__((address_space(3))) void *) (A + slot * RW), 16, 0, 0);
+        }
     };
     // level-l columns of this lane: interior columns j0 - 3 K + 3 l + 2 lane, +1
     bool cin0[K], cin1[K];
@@ -124,7 +173,7 @@ __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel
     }
     // stores: lanes 0 .. OUTW/2 - 1 write interior columns j0 + 2 lane, +1; the descriptor's range check drops the rest
     const unsigned store_off = lane < OUTW / 2 ? 16u * lane : 0x80000000u;
-    const unsigned row_bytes = (unsigned) (min(OUTW, a.n - j0) * 8);
+    const unsigned row_bytes = (unsigned) (max(min(OUTW, a.n - j0), 0) * 8);
     double *const out_strip = a.out + (j0 + 4);
 
     double pa[K][7], pb[K][7];  // rotating partial sums of the K levels, columns 2 lane / 2 lane + 1
@@ -139,7 +188,7 @@ __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel
 #pragma unroll
     for (int k = 0; k < D; ++k) issue(k, k);
 
-    const double *const winA = A + 2 * lane;
+    const double *const winA = A + (SHARE ? SHIFT + OUTW * wv : 0) + 2 * lane;
     const double *const winB = B + 2 * lane;
 
     // sl = ring slot of input row r (= phase when NS == 7)
@@ -151,22 +200,34 @@ __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel
         // about once in 400 runs.  With D >= 3 this wait does not stall on store acknowledgements: the loads of the
         // rows in between landed long ago, so the store of the previous step may still be in flight.)
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1) : "memory");
-        if (SYNC == 2) __builtin_amdgcn_s_barrier();
+        if (SYNC == 2 || SHARE) {  // SHARE: every wave's quarter of row r has landed once all have passed here
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
         auto wrap = [](int x) { return x >= NS ? x - NS : x; };
+        // Window of the NEXT level to run is fetched while the current one computes (PREFETCH: +16 VGPRs, hides the LDS
+        // latency inside the wave; every window of a step was written in the previous step, so the order is free)
+        d2 wnext[4];
+        auto fetch = [&](int l) {  // window of level l: its source row buffer, or the ring slot of input row r
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                wnext[q] = l >= 2 ? *reinterpret_cast<const d2 *>(winB + (l - 2) * kBRow + 2 * q)
+                                  : *reinterpret_cast<const d2 *>(winA + sl * RW + 2 * q);
+        };
+        if (PREFETCH) fetch(K);
         // ---- levels K .. 2: the level-(l-1) row completed in the previous step, from its row buffer ----
 #pragma unroll
         for (int l = K; l >= 2; --l) {
             const int R = (P + 7 * K - (l - 1)) % 7;  // (r - (l - 1)) mod 7: the rotation this level is at
             double win[8];
             {
-                d2 w4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const d2 *>(winB + (l - 2) * kBRow + 2 * q);
+                if (!PREFETCH) fetch(l);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    win[2 * q] = w4[q].x;
-                    win[2 * q + 1] = w4[q].y;
+                    win[2 * q] = wnext[q].x;
+                    win[2 * q + 1] = wnext[q].y;
                 }
+                if (PREFETCH) fetch(l - 1);
             }
             // R is a compile-time constant after unrolling; dispatch it to the template parameter
             auto run = [&](auto rot_tag) {
@@ -189,7 +250,7 @@ __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel
                     if ((l & 1) == 0 || DIRI) {
                         // halo cell of an even level: the source buffer's own value = input row r - 4 l + 1, columns
                         // 2 lane + 3 l, +1 of its ring slot (an aligned 16-byte piece for even l)
-                        const d2 h = *reinterpret_cast<const d2 *>(winA + wrap(sl + NS - (4 * l - 1) % NS) * kSInW + 3 * l);
+                        const d2 h = *reinterpret_cast<const d2 *>(winA + wrap(sl + NS - (4 * l - 1) % NS) * RW + 3 * l);
                         v.x = in0 ? v.x : h.x;
                         v.y = in1 ? v.y : h.y;
                     } else {
@@ -214,13 +275,11 @@ __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel
         {
             double win[8];
             {
-                d2 w4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) w4[q] = *reinterpret_cast<const d2 *>(winA + sl * kSInW + 2 * q);
+                if (!PREFETCH) fetch(1);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    win[2 * q] = w4[q].x;
-                    win[2 * q + 1] = w4[q].y;
+                    win[2 * q] = wnext[q].x;
+                    win[2 * q + 1] = wnext[q].y;
                 }
             }
             apply_row<EVAL, 7, P>(6, win, pa[0], pb[0], W, F);
@@ -234,7 +293,7 @@ __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel
             const bool in0 = row_in && cin0[1], in1 = row_in && cin1[1];
             if (DIRI) {
                 // source value: input row r - 3, columns 2 lane + 3, +1 (8-byte aligned only)
-                const double *cell = winA + wrap(sl + NS - 3) * kSInW + 3;
+                const double *cell = winA + wrap(sl + NS - 3) * RW + 3;
                 const double h0 = cell[0], h1 = cell[1];
                 v.x = in0 ? v.x : h0;
                 v.y = in1 ? v.y : h1;
@@ -254,7 +313,7 @@ __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel
 
     int sl0 = 0;  // ring slot of the first step of the group (always 0 when NS == 7)
     for (int g = 0; g < a.groups; ++g) {
-        if (SYNC == 1) __builtin_amdgcn_s_barrier();
+        if (SYNC == 1 && !SHARE) __builtin_amdgcn_s_barrier();
         const int r0 = 7 * g;
         auto slot = [&](int k) { return NS == 7 ? k : (sl0 + k >= NS ? sl0 + k - NS : sl0 + k); };
         step(r0 + 0, slot(0), std::integral_constant<int, 0>{});
@@ -270,7 +329,7 @@ __global__ __launch_bounds__(256, (K == 2 ? 4 : 3)) void stencil2d_stream_kernel
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int EVAL, int K, int D, int SYNC, bool DIRI>
+template <int EVAL, int K, int D, int SYNC, bool DIRI, bool PREFETCH, bool SHARE = false>
 hipError_t launch_stream_t(const Plan &p, const ArgsStream &a, hipStream_t s) {
     Taps49 w;
     for (int k = 0; k < 49; ++k) w.w[k] = p.w[k];
@@ -287,19 +346,29 @@ hipError_t launch_stream_t(const Plan &p, const ArgsStream &a, hipStream_t s) {
             f.v[0][k] = p.nest_a[k];
         }
     const long waves = (long) a.strips * a.chunks;
-    const long nblocks = (waves + 3) / 4;
+    const long nblocks = SHARE ? (long) ((a.strips + 3) / 4) * a.chunks : (waves + 3) / 4;
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((stencil2d_stream_kernel<EVAL, K, D, SYNC, DIRI>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w, f);
+    hipLaunchKernelGGL((stencil2d_stream_kernel<EVAL, K, D, SYNC, DIRI, PREFETCH, SHARE>), dim3((unsigned) nblocks), dim3(256), 0, s, a, w, f);
     return hipGetLastError();
 }
 
 template <int EVAL, int K>
 hipError_t launch_stream_e(const Plan &p, const ArgsStream &a, bool dirichlet, hipStream_t s) {
     const int sync = p.stream_sync;
-#define LORA_STREAM_GO(DD, DIRI)                                         \
-    return sync == 2   ? launch_stream_t<EVAL, K, DD, 2, DIRI>(p, a, s)   \
-           : sync == 1 ? launch_stream_t<EVAL, K, DD, 1, DIRI>(p, a, s)   \
-                       : launch_stream_t<EVAL, K, DD, 0, DIRI>(p, a, s);
+    // window prefetch (option stream_prefetch, K = 4): 1039 vs 1040 us per launch -- LDS latency is not what bounds it
+    if (p.stream_share) {  // one ring of whole rows per workgroup (D fixed: 3 rows in flight; 4 under Dirichlet)
+        if constexpr (K == 2) {
+            if (dirichlet) return launch_stream_t<EVAL, 2, 4, 1, true, false, true>(p, a, s);
+            return launch_stream_t<EVAL, 2, 4, 1, false, false, true>(p, a, s);
+        } else {
+            return launch_stream_t<EVAL, 4, 3, 1, false, false, true>(p, a, s);
+        }
+    }
+#define LORA_STREAM_GO(DD, DIRI)                                                                                  \
+    return sync == 2   ? launch_stream_t<EVAL, K, DD, 2, DIRI, false>(p, a, s)                                     \
+           : sync == 1 ? (K == 4 && p.stream_prefetch ? launch_stream_t<EVAL, K, DD, 1, DIRI, true>(p, a, s)       \
+                                                      : launch_stream_t<EVAL, K, DD, 1, DIRI, false>(p, a, s))     \
+                       : launch_stream_t<EVAL, K, DD, 0, DIRI, false>(p, a, s);
     if constexpr (K == 2) {
         if (dirichlet) {  // re-reads the input row three steps back: at most 4 rows in flight
             LORA_STREAM_GO(4, true)

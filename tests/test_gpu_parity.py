@@ -495,7 +495,8 @@ def test_fused_long_run_real_weights(L, O):
 @pytest.mark.parametrize("opts", [{"stream_rows": 8}, {"stream_rows": 50, "stream_depth": 2, "stream_sync": 0},
                                   {"stream_sync": 2}, {"stream_depth": 3, "stream_rows": 200},
                                   {"steps_per_launch": 2, "stream_depth": 6, "stream_rows": 29},
-                                  {"steps_per_launch": 2, "stream_depth": 2, "stream_sync": 2}])
+                                  {"steps_per_launch": 2, "stream_depth": 2, "stream_sync": 2},
+                                  {"stream_share": 1}, {"steps_per_launch": 2, "stream_share": 1}, {"stream_prefetch": 1}])
 def test_row_streaming_kernel_options_do_not_change_results(L, O, opts):
     """Chunk height, rows in flight and the strip-synchronising barriers of kernels_2d_stream.hip only move work
     around: random real data, bit-for-bit the same grid as the default configuration (and the oracle to rounding)."""
