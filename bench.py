@@ -365,14 +365,20 @@ def main():
     flops_per_launch = float(FLOPS_PER_POINT.get(shape, 0)) * local_points * apps
     tflops = flops_per_launch / launch_s / 1e12
     hbm_frac, flop_frac = achieved / HBM_PEAK_GBS, (tflops / FP64_PEAK_TFLOPS if not bf16 else 0.0)
-    traffic = None
+    traffic, pmc = None, {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     tkey = f"{shape}:{'x'.join(map(str, dims))}:{world}:{signature}"
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get(tkey)  # a miss stays null: never a number measured on another kernel
+            entry = json.load(open(tpath)).get(tkey)  # a miss stays null: never a number measured on another kernel
         except Exception:
-            traffic = None
+            entry = None
+        # an entry is either the HBM byte count alone (older profiles) or an object that also carries the pipe
+        # utilisation from the SQ counter passes of the same profile (tools/pmc_summary.py)
+        if isinstance(entry, dict):
+            traffic, pmc = entry.get("hbm_bytes"), entry
+        elif entry is not None:
+            traffic, pmc = entry, {}
 
     if rank == 0:
         res = {
@@ -414,6 +420,13 @@ def main():
                 # the same launch duration applied to the MEASURED bytes
                 "traffic_gbs": round(traffic / launch_s / 1e9, 1) if traffic else None,
                 "traffic_key": tkey,
+                # fraction of SIMD issue cycles spent on vector-ALU / matrix instructions, from the SQ counter passes of
+                # the profile `traffic` comes from (null when that profile has none): the utilisation of the pipe the
+                # "mfma" roof prices against
+                "valu_busy": pmc.get("valu_busy"),
+                "mfma_busy": pmc.get("mfma_busy"),
+                "waves_per_simd": pmc.get("waves_per_simd"),
+                "pmc_source": pmc.get("source"),
                 "launch_us": round(launch_s * 1e6, 2),
                 "launches": launches,
                 "bytes_per_launch": round(bytes_per_launch),

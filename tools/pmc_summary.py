@@ -68,6 +68,17 @@ def main():
                 e["hbm_read_bytes_per_launch"] = fetch
                 e["hbm_write_bytes_per_launch"] = write
                 e["hbm_bytes_per_launch"] = fetch + write
+            # pipe utilisation (MI355X_MICROARCH.md: SQ_WAVE_CYCLES / SQ_ACTIVE_INST_* count quad-cycles summed over waves,
+            # SQ_VALU_MFMA_BUSY_CYCLES cycles summed over SIMDs, GRBM_GUI_ACTIVE cycles summed over the 8 XCDs)
+            if "GRBM_GUI_ACTIVE" in cs and "SQ_WAVE_CYCLES" in cs:
+                cyc = e["GRBM_GUI_ACTIVE"]["mean"] / 8.0             # shader cycles of the launch
+                simd_quads = cyc / 4.0 * 1024.0                       # quad-cycles available on 256 CUs x 4 SIMDs
+                e["clock_ghz"] = cyc / e["_mean_duration_ns_under_pmc"]
+                e["waves_per_simd"] = e["SQ_WAVE_CYCLES"]["mean"] / simd_quads
+                if "SQ_ACTIVE_INST_VALU" in cs:
+                    e["valu_busy"] = e["SQ_ACTIVE_INST_VALU"]["mean"] / simd_quads
+                if "SQ_VALU_MFMA_BUSY_CYCLES" in cs:
+                    e["mfma_busy"] = e["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (cyc * 1024.0)
             summary[k] = e
         out = os.path.join(prof, f"{args.tag}_pmc.json")
         json.dump(summary, open(out, "w"), indent=1, sort_keys=True)
@@ -77,7 +88,11 @@ def main():
             t = json.load(open(tpath)) if os.path.exists(tpath) else {}
             best = max(summary.values(), key=lambda e: e.get("hbm_bytes_per_launch", 0))
             if "hbm_bytes_per_launch" in best:
-                t[args.traffic_key] = round(best["hbm_bytes_per_launch"])
+                t[args.traffic_key] = {"hbm_bytes": round(best["hbm_bytes_per_launch"]),
+                                       "valu_busy": round(best["valu_busy"], 3) if "valu_busy" in best else None,
+                                       "mfma_busy": round(best["mfma_busy"], 3) if "mfma_busy" in best else None,
+                                       "waves_per_simd": round(best["waves_per_simd"], 2) if "waves_per_simd" in best else None,
+                                       "source": f"profiles/{args.tag}_pmc.json"}
                 json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
                 print("traffic", args.traffic_key, t[args.traffic_key])
 
