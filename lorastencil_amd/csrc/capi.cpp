@@ -295,12 +295,21 @@ void plan_refresh(Plan &p) {
         // two applications per launch (kernels_3d_fused.hip): fp64 tiled path; default, as in 2D (star3d1r 512^3
         // 499 vs 288 GStencils/s, box3d1r 768^3 523 vs 300)
         p.steps_per_launch = (!p.generic && p.steps_per_launch_req != 1) ? 2 : 1;
+        // fp64: THREE applications per launch in the plane-streaming kernel (kernels_3d_stream.hip) -- the grid is read
+        // and written once per three sweeps.  An odd count needs no halo copies: launch k starts at global step 3 k and
+        // runs on the reference's own buffer state (lora_plan_run)
+        const bool stream3 = p.dtype != LORA_BF16 && !p.generic && p.stream3 != 0;
+        // (the 27-tap box stays at two: its third level makes the launch VALU- and LDS-bound, 465 against 499 GStencils/s
+        // at 768^3 -- asked for explicitly it is available)
+        if (stream3 && p.steps_per_launch == 2 && p.boundary != LORA_BC_PERIODIC &&
+            (p.steps_per_launch_req == 3 || (p.steps_per_launch_req == 0 && p.tapset == TAPS3D_STAR)))
+            p.steps_per_launch = 3;
         p.kernel_name = (p.dtype == LORA_BF16)
                             ? (p.steps_per_launch == 2 ? (p.variant == LORA_VARIANT_MFMA ? kernel_name_3d_bf16_mfma2(p)
                                                                                           : kernel_name_3d_bf16_fused2(p))
                                                        : kernel_name_3d_bf16(p))
                         : p.generic            ? kernel_name_generic(p)
-                        : p.steps_per_launch == 2 ? kernel_name_3d_fused2(p)
+                        : p.steps_per_launch >= 2 ? (stream3 ? kernel_name_3d_stream(p) : kernel_name_3d_fused2(p))
                                                   : kernel_name_3d(p);
     } else {
         p.tapset = 0;
@@ -342,6 +351,23 @@ static int step_region(Plan &p, const void *d_in, void *d_out, int begin, int en
         e = launch_3d(p, in, out, begin, end, s);
     if (e != hipSuccess) {
         set_last_error("kernel launch", e);
+        return LORA_EHIP;
+    }
+    return LORA_OK;
+}
+
+// Three applications (3D fp64, plane-streaming kernel) starting at a global step of the given parity; `d_halo` is a
+// buffer that carries the caller's halo (what even global levels see outside the interior).
+static int step3_natural(Plan &p, const void *d_in, void *d_out, const void *d_halo, int parity, int begin, int end,
+                         void *stream) {
+    if (!(p.ndim == 3 && p.dtype != LORA_BF16 && !p.generic && p.stream3)) return LORA_EUNSUPPORTED;
+    if (int rc = check_buffers(d_in, d_out)) return rc;
+    if (d_in == d_out || !d_halo || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
+    const hipError_t e = launch_3d_stream(p, 3, static_cast<const double *>(d_in), static_cast<double *>(d_out),
+                                          static_cast<const double *>(d_halo), parity, begin, end,
+                                          static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        set_last_error("fused 3-step kernel launch", e);
         return LORA_EHIP;
     }
     return LORA_OK;
@@ -545,6 +571,16 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "stream_depth")) {
         if (value < 2 || value > 6) return LORA_EINVAL;
         p.stream_depth = value;
+    } else if (!std::strcmp(key, "stream3")) {
+        p.stream3 = value ? 1 : 0;
+    } else if (!std::strcmp(key, "stream3_waves")) {
+        if (value != 4 && value != 6 && value != 7 && value != 8) return LORA_EINVAL;
+        p.stream3_waves = value;
+    } else if (!std::strcmp(key, "stream3_pipe")) {
+        p.stream3_pipe = value ? 1 : 0;
+    } else if (!std::strcmp(key, "stream3_slots")) {
+        if (value < 0 || value > 4) return LORA_EINVAL;
+        p.stream3_slots = value;
     } else if (!std::strcmp(key, "stream_share")) {
         p.stream_share = value ? 1 : 0;
     } else if (!std::strcmp(key, "stream_prefetch")) {
@@ -569,7 +605,7 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         p.separable = value;
     } else if (!std::strcmp(key, "ablate")) {
 #ifdef LORA_DIAGNOSTICS
-        p.ablate = value & 3;
+        p.ablate = value & 63;
 #else
         g_last_error = "option \"ablate\" exists only in -DLORA_DIAGNOSTICS builds";
         return LORA_EINVAL;  // wrong-results timing experiments are not part of the shipped library
@@ -583,11 +619,12 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         if (value != 0 && value != 6 && value != 8 && value != 10) return LORA_EINVAL;
         p.fused_rows_req = value;
     } else if (!std::strcmp(key, "steps_per_launch")) {
-        if (value < 0 || value > 8 || (value & (value - 1))) return LORA_EINVAL;  // 0 (auto), 1, 2, 4, 8
+        const bool three = value == 3 && p.ndim == 3 && p.dtype != LORA_BF16;  // 3D fp64 plane-streaming kernel
+        if (value < 0 || value > 8 || ((value & (value - 1)) && !three)) return LORA_EINVAL;  // 0 (auto), 1, 2, 4, 8
         const bool fusable = (p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && (!p.generic || p.stream2)) ||
                              (p.ndim == 3 && !p.generic) || p.ndim == 1;
         if (value >= 2 && !fusable) return LORA_EUNSUPPORTED;
-        if (value > 2 && p.ndim == 3) return LORA_EUNSUPPORTED;  // 3D kernels fuse two applications
+        if (value > 2 && p.ndim == 3 && !three) return LORA_EUNSUPPORTED;  // 3D: two; three in the fp64 plane-streaming kernel
         if (value > 4 && p.ndim == 2) return LORA_EUNSUPPORTED;  // 2D: two, or four in the row-streaming kernel
         p.steps_per_launch_req = value;
     } else if (!std::strcmp(key, "fused_pipeline")) {
@@ -619,6 +656,14 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.use_graph;
     else if (!std::strcmp(key, "stream"))
         *value = p.stream2;
+    else if (!std::strcmp(key, "stream3"))
+        *value = p.stream3;
+    else if (!std::strcmp(key, "stream3_waves"))
+        *value = p.stream3_waves;
+    else if (!std::strcmp(key, "stream3_slots"))
+        *value = p.stream3_slots;
+    else if (!std::strcmp(key, "stream3_pipe"))
+        *value = p.stream3_pipe;
     else if (!std::strcmp(key, "stream_rows"))
         *value = p.stream_rows;
     else if (!std::strcmp(key, "stream_depth"))
@@ -682,6 +727,13 @@ const char *lora_plan_kernel_signature(const lora_plan *plan) {
                       p.panel_width);
     else if (k == "stencil2d_mfma_kernel")
         std::snprintf(buf, sizeof buf, "rank=%d,panel=%d", p.lowrank.rank, p.panel_width);
+    else if (k == "stencil3d_stream_kernel")
+{
+        const int K = p.steps_per_launch, pipe = (K == 2 || p.stream3_pipe) ? 1 : 0;
+        const int nw = lora::stream3_waves(K, pipe, p.stream3_waves);
+        std::snprintf(buf, sizeof buf, "taps=%d,k=%d,waves=%d,slots=%d,pipe=%d,fzc=%d,bc=%d", p.tapset, K, nw,
+                      lora::stream3_slots(K, nw, pipe, p.stream3_slots), pipe, p.fused_z_chunk, p.boundary);
+    }
     else if (p.ndim == 3 && p.dtype == LORA_BF16)
         std::snprintf(buf, sizeof buf, "taps=%d,zc=%d,fzc=%d,cpl=%d,dma=%d,pipe=%d,bc=%d", p.tapset, p.z_chunk,
                       p.fused_z_chunk, p.cols_per_lane, p.lds_dma, p.fused_pipeline, p.boundary);
@@ -724,6 +776,10 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
                              ? (p.variant == LORA_VARIANT_MFMA
                                     ? lora::launch_3d_bf16_mfma2(p, d_in, d_out, begin, end, static_cast<hipStream_t>(stream))
                                     : lora::launch_3d_bf16_fused2(p, d_in, d_out, begin, end, static_cast<hipStream_t>(stream)))
+                         : p.stream3
+                             ? lora::launch_3d_stream(p, 2, static_cast<const double *>(d_in), static_cast<double *>(d_out),
+                                                      static_cast<const double *>(d_in), 0, begin, end,
+                                                      static_cast<hipStream_t>(stream))
                              : lora::launch_3d_fused2(p, static_cast<const double *>(d_in), static_cast<double *>(d_out),
                                                       begin, end, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) {
@@ -772,6 +828,8 @@ int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int b
         }
         return LORA_OK;
     }
+    if (p.ndim == 3 && p.steps_per_launch == 3)  // an even global step: level 1 has the zero halo, level 2 the source's
+        return lora::step3_natural(p, d_in, d_out, d_in, 0, begin, end, stream);
     if (p.ndim != 1) return lora_plan_step2_region(plan, d_in, d_out, begin, end, stream);
     if (int rc = lora::check_buffers(d_in, d_out)) return rc;
     if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end || (begin & 1)) return LORA_EINVAL;
@@ -898,7 +956,29 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
     const int K = p.steps_per_launch;  // applications per fused launch: 2 (2D, 3D) or 2 / 4 / 8 (1D)
     const bool can_fuse = K >= 2 && (!p.generic || (p.ndim == 2 && p.stream2 && p.boundary == LORA_BC_REFERENCE)) &&
                           ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) || p.ndim == 3 || p.ndim == 1);
-    FusedSchedule fs = fused_schedule(plan, times, can_fuse);
+    FusedSchedule fs;
+    const bool natural3 = can_fuse && p.ndim == 3 && K == 3;
+    if (natural3) {
+        // Three applications per launch (3D fp64): launch k covers global steps 3 k + 1 .. 3 k + 3, reading buffer
+        // k mod 2 and writing the other one -- exactly where the step-by-step driver has these levels, so the launches
+        // run on the reference's own buffer state (buffer 0: the caller's halo, buffer 1: zeros; both the caller's
+        // under the Dirichlet option): no halo copies, no parity constraint on the number of launches, no scratch grid.
+        // The kernel is told the parity of its first step (which of its inner levels sees which halo).
+        const int nk = times / 3;
+        if (nk > 0) {
+            if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
+            if (!dirichlet)
+                if (int rc = halo(buf[1], nullptr, lora::HALO_ZERO, "halo reset")) return rc;
+            for (int k = 0; k < nk; ++k)
+                if (int rc = lora::step3_natural(p, buf[k % 2], buf[(k + 1) % 2], buf[0], k & 1, 0, p.dims[0], stream))
+                    return rc;
+            done = 3 * nk;
+            if (marks) marks->fused_launches = nk;
+        }
+        mark(1);
+    } else {
+        fs = fused_schedule(plan, times, can_fuse);
+    }
     if (fs.nk + fs.n2 > 0) {
         // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes another one, so
         // while fused launches run every physical buffer carries buffer 0's halo; the data must end in buffer 0, after
@@ -932,7 +1012,7 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
         done = K * fs.nk + 2 * fs.n2;
         if (marks) marks->fused_launches = fs.nk;
         if (marks) marks->two_launches = fs.n2;
-    } else {
+    } else if (!natural3) {
         mark(1);
     }
     mark(2);

@@ -75,6 +75,10 @@ struct Plan {
     int stream_sync = 1;      // ... s_barrier per 7 rows (1) / per row (2) keeps a workgroup's four strips in step
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
     int fused_pipeline = 0;   // 3D bf16 fused: 1 = level 2 one plane behind level 1, one barrier per plane (no gain measured)
+    int stream3 = 1;          // 3D fp64 fused: plane-streaming kernel (kernels_3d_stream.hip: 2 or 3 applications per launch) or the tile kernel (0, 2 applications)
+    int stream3_waves = 8;    // 3D plane-streaming kernel: waves per workgroup: 8 / 7 / 6 (one workgroup per CU) or 4 (two); output tiles of 8 x waves - 2 (K - 1) rows x 60 columns
+    int stream3_pipe = 0;     // 3D plane-streaming kernel: 1 = every level consumes what was published one step earlier (one barrier per step, two buffers per level)
+    int stream3_slots = 0;    // 3D plane-streaming kernel: input plane slots of the LDS ring (0 = as many as fit)
     int fused_z_chunk = 0;    // 3D fused: output planes per workgroup (0 = auto: 32, shorter on small grids)
     int steps_per_launch_req = 0;  // 0 = auto, 1, 2 (2D / 3D), 4 (2D row-streaming kernel), 2 / 4 / 8 (1D)
     int steps_per_launch = 1;      // resolved
@@ -118,6 +122,11 @@ hipError_t launch_3d(const Plan &p, const double *in, double *out, int begin, in
 // two applications per launch, level 1 in LDS (fp64, reference boundary: level-1 halo = 0)
 hipError_t launch_3d_fused2(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 const char *kernel_name_3d_fused2(const Plan &p);
+hipError_t launch_3d_stream(const Plan &p, int K, const double *in, double *out, const double *halo_src, int parity,
+                            int begin, int end, hipStream_t s);
+const char *kernel_name_3d_stream(const Plan &p);
+int stream3_slots(int K, int waves, int pipe, int requested);
+int stream3_waves(int K, int pipe, int requested);
 // any size, any taps (odd innermost extents): one thread per point
 hipError_t launch_2d_generic(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 hipError_t launch_3d_generic(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include "device_common.h"
+#include "planes_3d.h"
 
 namespace lora {
 
@@ -40,11 +41,6 @@ constexpr int kOutW = kMidW - 4;             // output columns per tile
 constexpr int kInW = kMidW + 4;              // staged input columns (also the LDS row stride of both tiles)
 constexpr int kInChunks = kInW / 2;          // 16-byte pieces per staged row
 
-template <int TAPSET>
-__host__ __device__ constexpr bool tap_on3(int dz, int dy, int dx) {
-    return TAPSET == TAPS3D_BOX ? true : (((dz != 1) + (dy != 1) + (dx != 1)) <= 1);
-}
-
 struct ArgsF3 {
     const double *in;
     double *out;
@@ -56,31 +52,6 @@ struct ArgsF3 {
     int tiles_x, tiles_y;
     int dirichlet;  // level-1 cells outside the interior keep the source's halo value instead of 0
 };
-
-// Row `j` of a strip's window (6 doubles, the lane's columns are elements 2 and 3) added, weighted per dz / dy / dx,
-// to the rotating accumulator sets: a plane of phase PH feeds result plane slot (PH - dz) mod 3.
-template <int TAPSET, int RY, int PH>
-__device__ __forceinline__ void scatter_row(double (&x0)[3][RY], double (&x1)[3][RY], const double (&win)[6], int j,
-                                            const Taps27 &W) {
-#pragma unroll
-    for (int dz = 0; dz < 3; ++dz) {
-        const int s = (PH - dz + 3) % 3;
-#pragma unroll
-        for (int r = 0; r < RY; ++r) {
-            const int dy = j - r;
-            if (dy >= 0 && dy < 3) {
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    if (tap_on3<TAPSET>(dz, dy, dx)) {
-                        const double wt = W.w[dz * 9 + dy * 3 + dx];
-                        x0[s][r] = fma(wt, win[dx + 1], x0[s][r]);
-                        x1[s][r] = fma(wt, win[dx + 2], x1[s][r]);
-                    }
-                }
-            }
-        }
-    }
-}
 
 // DIRICHLET is a template flag, not a run-time one: the halo reload it adds to the publish step costs registers that
 // the reference-boundary instantiation should not pay (bf16: 137 instead of 128 VGPRs = 3 instead of 4 per CU).

@@ -539,6 +539,7 @@ int lora_slab_create(lora_slab **out, const lora_slab_desc *d, const lora_slab_c
         (void) lora_plan_get_option(probe, "steps_per_launch", &apps);
         lora_plan_destroy(probe);
         if (d->flags & LORA_SLAB_NO_FUSION) apps = 1;
+        if (nd == 3 && apps > 2) apps = 2;  // slab launches start at even steps on buffers that both carry the halo
         while (apps > 1 && splitting && thinnest < s->radius * apps) apps = (nd == 2 && apps == 4) ? 2 : 1;
     }
     s->apps = apps;

@@ -148,6 +148,10 @@ class HipStepper:
             self.plan.set_boundary(boundary)  # fused launches: intermediate halo cells keep the source's values
         if boundary == "periodic":
             self.plan.set_option("steps_per_launch", 1)  # a fused launch would need the wrap of its inner levels
+        elif len(layout.local_dims) == 3 and self.plan.get_option("steps_per_launch") > 2:
+            # the single-GPU driver fuses three sweeps per launch on the reference's alternating buffer state; slab
+            # launches start at even steps on buffers that both carry the halo: two per launch
+            self.plan.set_option("steps_per_launch", 2)
         # launches go to the stream that is current when the driver is built (looked up once: at 8 GPUs a launch is
         # ~100 us of GPU time, so per-call host work matters)
         self.torch_stream = torch.cuda.current_stream() if torch.cuda.is_available() else None

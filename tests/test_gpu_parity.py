@@ -356,7 +356,7 @@ def test_fused_step2_direct_call_and_regions(L, O):
     with pytest.raises(L.LoraError):
         L.Plan("star2d1r", (64, 64)).set_option("steps_per_launch", 8)  # 2D fuses two or four applications
     with pytest.raises(L.LoraError):
-        L.Plan("star3d1r", (8, 8, 64)).set_option("steps_per_launch", 4)  # 3D kernels fuse two
+        L.Plan("star3d1r", (8, 8, 64)).set_option("steps_per_launch", 4)  # 3D kernels fuse two or three
     with pytest.raises(L.LoraError):
         L.Plan("1d1r", (64,)).set_option("steps_per_launch", 3)
 
@@ -425,22 +425,133 @@ def test_1d_fused_k_step_launches_equal_step_by_step(L, O, shape, n):
     assert np.array_equal(dst.cpu().numpy()[:4], b[:4]) and np.array_equal(dst.cpu().numpy()[-4:], b[-4:])
 
 
+# fused 3D fp64 launches: the plane-streaming kernel (three / two applications, its workgroup shapes and the one-barrier
+# pipeline) and the round-1 tile kernel
+FUSED_3D = {
+    "default": {},
+    "stream3": {"steps_per_launch": 3},
+    "stream3_w4": {"steps_per_launch": 3, "stream3_waves": 4},
+    "stream3_w7": {"steps_per_launch": 3, "stream3_waves": 7},
+    "stream3_w6s3": {"steps_per_launch": 3, "stream3_waves": 6, "stream3_slots": 3},
+    "stream3_pipe": {"steps_per_launch": 3, "stream3_pipe": 1},
+    "stream2": {"steps_per_launch": 2},
+    "stream2_w4": {"steps_per_launch": 2, "stream3_waves": 4},
+    "stream2_w7pipe": {"steps_per_launch": 2, "stream3_waves": 7, "stream3_pipe": 1},
+    "tile2": {"stream3": 0, "steps_per_launch": 2},
+}
+
+
 @pytest.mark.parametrize("shape", ["star3d1r", "box3d1r"])
 @pytest.mark.parametrize("dims", [(40, 60, 128), (9, 31, 62), (37, 29, 190), (3, 5, 2), (70, 64, 64)])
-def test_3d_fused_two_step_launches_equal_step_by_step(L, O, shape, dims):
-    """kernels_3d_fused.hip: two applications per launch with time level 1 in LDS.  Same taps in the same order at
-    both levels, so the whole padded buffer (interior and the halo state the step-by-step driver leaves behind)
-    equals the oracle bit for bit while values are exact integers, and to rounding afterwards."""
+@pytest.mark.parametrize("cfg", list(FUSED_3D))
+def test_3d_fused_launches_equal_step_by_step(L, O, shape, dims, cfg):
+    """kernels_3d_stream.hip (three or two applications per launch, inner time levels in LDS) and kernels_3d_fused.hip
+    (two).  Same taps in the same order at every level, so the whole padded buffer (interior and the halo state the
+    step-by-step driver leaves behind) equals the oracle bit for bit while values are exact integers, and to rounding
+    afterwards.  Three-application launches run on the reference's alternating buffer state: any step count, odd
+    numbers of launches included."""
     a = O.reference_input(shape, dims)
-    assert L.Plan(shape, dims).set_option("steps_per_launch", 2).kernel_name == "stencil3d_fused2_kernel"
-    for t in (4, 5, 6, 7, 9):
+    opts = FUSED_3D[cfg]
+    plan = L.Plan(shape, dims)
+    for k, v in opts.items():
+        plan.set_option(k, v)
+    if cfg == "default":
+        assert plan.get_option("steps_per_launch") == (3 if shape == "star3d1r" else 2)
+    if cfg != "default":
+        assert plan.get_option("steps_per_launch") == opts["steps_per_launch"]
+    assert plan.kernel_name == ("stencil3d_fused2_kernel" if cfg == "tile2" else "stencil3d_stream_kernel")
+    for t in (3, 4, 5, 6, 7, 9):
         exp = O.run(shape, a, t)
         for zc in (0, 1, 3, 8):
-            got = plan_run(L, shape, a, t, options={"steps_per_launch": 2, "fused_z_chunk": zc})
+            got = plan_run(L, shape, a, t, options=dict(opts, fused_z_chunk=zc))
             if np.abs(exp).max() < 2.0 ** 53:
-                assert np.array_equal(got, exp), f"{shape} {dims} t={t} zc={zc}"
+                assert np.array_equal(got, exp), f"{shape} {dims} {cfg} t={t} zc={zc}"
             else:
-                assert rel_err(got, exp) < 1e-13, f"{shape} {dims} t={t} zc={zc}"
+                assert rel_err(got, exp) < 1e-13, f"{shape} {dims} {cfg} t={t} zc={zc}"
+
+
+@pytest.mark.parametrize("shape", ["star3d1r", "box3d1r"])
+@pytest.mark.parametrize("boundary", ["reference", "dirichlet"])
+def test_3d_three_step_launches_real_weights_both_boundaries(L, O, shape, boundary):
+    """Three applications per launch on real data, both boundaries, against single sweeps bit for bit (same tap order)
+    and against the oracle to rounding; plus the public stepk entry (an even global step: level 1 sees the zero halo,
+    level 2 the source's)."""
+    import torch
+
+    rng = np.random.default_rng(17)
+    dims = (21, 70, 124)
+    a = rng.standard_normal(O.padded_shape(shape, dims))
+    a[0] = rng.standard_normal(a[0].shape)  # a non-trivial caller halo
+    w = rng.standard_normal(27) if shape == "box3d1r" else O.effective_weights(shape) / 8.0
+    w = w / np.abs(w).sum()
+
+    def run(times, opts):
+        plan = L.Plan(shape, dims).set_weights(w)
+        if boundary != "reference":
+            plan.set_boundary(boundary)
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        b0 = torch.from_numpy(a).cuda()
+        b1 = torch.zeros_like(b0)
+        plan.run(b0, b1, times)
+        torch.cuda.synchronize()
+        return (b0, b1)[times % 2].cpu().numpy(), plan
+
+    for t in (3, 6, 8, 10):
+        single, _ = run(t, {"steps_per_launch": 1})
+        for opts in ({"steps_per_launch": 3}, {"steps_per_launch": 3, "stream3_waves": 4, "fused_z_chunk": 5},
+                     {"steps_per_launch": 3, "stream3_pipe": 1}):
+            got, plan = run(t, opts)
+            assert plan.kernel_name == "stencil3d_stream_kernel" and plan.get_option("steps_per_launch") == 3
+            assert np.array_equal(got, single), (shape, boundary, t, opts)
+        exp = O.run_bc(shape, a, t, boundary, weights=w) if boundary != "reference" else O.run(shape, a, t, weights=w)
+        assert rel_err(single, exp) < 1e-13
+    if boundary == "reference":
+        plan = L.Plan(shape, dims).set_weights(w).set_option("steps_per_launch", 3)
+        src = torch.from_numpy(a).cuda()
+        dst = torch.from_numpy(a).cuda()
+        dst[1:-1, 2:-2, 4:-4] = -1.0
+        plan.stepk(src, dst)
+        torch.cuda.synchronize()
+        whole = dst.cpu().numpy()
+        exp3 = O.run(shape, a, 3, weights=w)
+        assert rel_err(whole[1:-1, 2:-2, 4:-4], exp3[1:-1, 2:-2, 4:-4]) < 1e-13
+        assert np.array_equal(whole[0], a[0]) and np.array_equal(whole[:, :2], a[:, :2])  # halo untouched
+        dst[1:-1, 2:-2, 4:-4] = -1.0
+        for b, e in ((15, 21), (0, 4), (4, 15)):
+            plan.stepk_region(src, dst, b, e)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), whole)  # plane ranges == one launch, bit for bit
+
+
+@pytest.mark.parametrize("shape,dims", [("star3d1r", (200, 310, 372)), ("box3d1r", (150, 250, 300))])
+def test_3d_stream_kernel_at_scale_equals_single_sweeps(L, shape, dims):
+    """Several workgroups per CU and several rounds of them: a wave overtaking its neighbour (a missing barrier between
+    publishing a level and the next overwrite of it) shows only at this scale -- the first two-application form of the
+    kernel passed every small case and failed here.  Every workgroup shape, bit for bit against single sweeps."""
+    import torch
+
+    w = L.effective_weights(shape)
+    w = w / w.sum()
+    torch.manual_seed(3)
+    a = torch.randn(L.padded_shape(shape, dims), dtype=torch.float64, device="cuda")
+
+    def run(opts, times):
+        plan = L.Plan(shape, dims).set_weights(w)
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        b0 = a.clone()
+        b1 = torch.zeros_like(b0)
+        plan.run(b0, b1, times)
+        torch.cuda.synchronize()
+        return (b0, b1)[times % 2]
+
+    ref = run({"steps_per_launch": 1}, 6)
+    for k in (3, 2):
+        for wv in (8, 7, 6, 4):
+            for extra in ({}, {"stream3_pipe": 1}):
+                got = run(dict({"steps_per_launch": k, "stream3_waves": wv}, **extra), 6)
+                assert torch.equal(got, ref), (shape, k, wv, extra)
 
 
 def test_3d_fused_step2_regions_and_real_weights(L, O):
@@ -455,6 +566,7 @@ def test_3d_fused_step2_regions_and_real_weights(L, O):
             w /= np.abs(w).sum()
         exp = O.run(shape, a, 2, weights=w)  # buffer 0 after two sweeps: interior + the input halo
         plan = L.Plan(shape, dims).set_weights(w).set_option("steps_per_launch", 2)
+        assert plan.kernel_name == "stencil3d_stream_kernel"
         src = torch.from_numpy(a).cuda()
         dst = torch.from_numpy(a).cuda()
         dst[1:-1, 2:-2, 4:-4] = -1.0
@@ -1033,7 +1145,7 @@ def test_full_size_constant_field_and_windows(L, O, shape, dims):
     # (4) the fused kernels == single sweeps through buffers whose halo alternates between 0 and the input's, everywhere
     #     (small integers: exact whatever the summation order of the low-rank evaluation)
     k_apps = plan.get_option("steps_per_launch")
-    assert k_apps == (4 if len(dims) == 2 else 2)
+    assert k_apps == (4 if len(dims) == 2 else (3 if shape == "star3d1r" else 2))
     del dst
     two = src.clone()                 # buffer 0 again after two sweeps: the input's halo, new interior
     plan.step(dst2, two)              # dst2 = sweep(src) with a zero halo
@@ -1051,6 +1163,13 @@ def test_full_size_constant_field_and_windows(L, O, shape, dims):
         plan.stepk(src, fused)
         torch.cuda.synchronize()
         assert torch.equal(fused, four)
+    if k_apps == 3:                   # the default 3D star launch: three applications (interior; its halo is the output's)
+        three = torch.zeros_like(src)
+        plan.step(two, three)
+        fused.zero_()
+        plan.stepk(src, fused)
+        torch.cuda.synchronize()
+        assert torch.equal(fused, three)
 
 
 @pytest.mark.parametrize("shape,dims,dtype", [

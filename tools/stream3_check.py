@@ -1,0 +1,111 @@
+#!/usr/bin/env python3
+"""Development tool: the 3D plane-streaming kernel (three / two applications per launch) against single sweeps, bit for
+bit, on ragged grids and both boundaries; then timings on the BASELINE grids.  Writes gpurun_out/stream3_check.jsonl."""
+import argparse
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import lorastencil_amd as L  # noqa: E402
+
+
+def run(shape, dims, w, a, times, opts, boundary):
+    ps = L.padded_shape(shape, dims)
+    plan = L.Plan(shape, dims).set_weights(w)
+    if boundary != "reference":
+        plan.set_boundary(boundary)
+    for k, v in opts.items():
+        plan.set_option(k, v)
+    b0 = torch.from_numpy(a).cuda()
+    b1 = torch.zeros(ps, dtype=torch.float64, device="cuda")
+    plan.run(b0, b1, times)
+    torch.cuda.synchronize()
+    return (b0, b1)[times % 2].cpu().numpy(), plan.kernel_signature
+
+
+def parity():
+    rng = np.random.default_rng(11)
+    bad = n = 0
+    for shape in ("star3d1r", "box3d1r"):
+        for dims in ((8, 8, 8), (20, 64, 60), (7, 61, 62), (33, 70, 130), (5, 130, 58), (40, 9, 200), (64, 64, 64)):
+            w = L.effective_weights(shape)
+            w = w / w.sum()
+            a = rng.standard_normal(L.padded_shape(shape, dims))
+            for boundary in ("reference", "dirichlet"):
+                for times in (3, 4, 6, 7, 11):
+                    ref, _ = run(shape, dims, w, a, times, {"steps_per_launch": 1}, boundary)
+                    for opts in ({}, {"stream3_waves": 4}, {"steps_per_launch": 2}, {"steps_per_launch": 2, "stream3_waves": 4},
+                                 {"fused_z_chunk": 5}, {"fused_z_chunk": 3, "stream3_waves": 4}, {"stream3_waves": 7},
+                                 {"stream3_waves": 6}, {"stream3_waves": 6, "stream3_slots": 3, "fused_z_chunk": 4},
+                                 {"stream3_waves": 7, "steps_per_launch": 2}, {"stream3_waves": 6, "steps_per_launch": 2},
+                                 {"stream3_waves": 7, "stream3_slots": 2}, {"stream3_slots": 2, "steps_per_launch": 2},
+                                 {"stream3_pipe": 1}, {"stream3_pipe": 1, "fused_z_chunk": 4},
+                                 {"stream3_pipe": 1, "steps_per_launch": 2},
+                                 {"stream3_pipe": 1, "steps_per_launch": 2, "stream3_waves": 7, "fused_z_chunk": 3},
+                                 {"stream3_pipe": 1, "steps_per_launch": 2, "stream3_waves": 6},
+                                 {"stream3_pipe": 1, "steps_per_launch": 2, "stream3_waves": 4}):
+                        got, sig = run(shape, dims, w, a, times, opts, boundary)
+                        n += 1
+                        if not np.array_equal(ref, got):
+                            bad += 1
+                            d = np.argwhere(ref != got)
+                            print("MISMATCH", shape, dims, boundary, times, opts, sig, len(d), "cells, first", d[:3].tolist(),
+                                  "max", float(np.abs(ref - got).max()), flush=True)
+    print(f"parity: {n - bad}/{n} bit-identical to single sweeps", flush=True)
+    return bad
+
+
+def timing(out):
+    for shape, dims in (("star3d1r", (512, 512, 512)), ("box3d1r", (768, 768, 768)), ("box3d1r", (512, 512, 512)),
+                        ("star3d1r", (768, 768, 768))):
+        w = L.effective_weights(shape)
+        w = w / w.sum()
+        ps = L.padded_shape(shape, dims)
+        src = torch.randint(0, 100, ps, device="cuda").to(torch.float64)
+        dst = torch.zeros_like(src)
+        pts = dims[0] * dims[1] * dims[2]
+        cases = [{"stream3": 0}, {"steps_per_launch": 2}, {"steps_per_launch": 3}, {"steps_per_launch": 3, "stream3_waves": 4},
+                 {"steps_per_launch": 3, "stream3_waves": 4, "fused_z_chunk": 32},
+                 {"steps_per_launch": 3, "stream3_pipe": 1}, {"steps_per_launch": 3, "stream3_pipe": 1, "fused_z_chunk": 64},
+                 {"steps_per_launch": 3, "stream3_pipe": 1, "fused_z_chunk": 32},
+                 {"steps_per_launch": 2, "stream3_pipe": 1}, {"steps_per_launch": 2, "stream3_pipe": 1, "stream3_waves": 7},
+                 {"steps_per_launch": 2, "stream3_pipe": 1, "stream3_waves": 6},
+                 {"steps_per_launch": 2, "stream3_pipe": 1, "stream3_waves": 4},
+                 {"steps_per_launch": 2, "stream3_pipe": 1, "stream3_waves": 4, "fused_z_chunk": 32}]
+        for opts in cases:
+            plan = L.Plan(shape, dims).set_weights(w)
+            for k, v in opts.items():
+                plan.set_option(k, v)
+            apps = plan.get_option("steps_per_launch")
+            plan.stepk(src, dst)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                plan.stepk(src, dst)
+                plan.stepk(dst, src)
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) / 1e3 / 10
+            rec = {"shape": shape, "dims": dims, "opts": opts, "kernel": plan.kernel_signature, "apps": apps,
+                   "us": round(t * 1e6, 1), "gstencils": round(apps * pts / t / 1e9, 1)}
+            print(json.dumps(rec), flush=True)
+            out.write(json.dumps(rec) + "\n")
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--no-timing", action="store_true")
+    args = ap.parse_args()
+    bad = parity()
+    if bad == 0 and not args.no_timing:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "stream3_check.jsonl"), "w") as f:
+            timing(f)
+    sys.exit(1 if bad else 0)
