@@ -172,13 +172,18 @@ int lora_set_default_boundary(int boundary);
  * BASELINE config 3 asks for 200).  Not reference behaviour.  Returns the previous value. */
 int lora_set_default_normalize(int on);
 /* Integer options.  Results never depend on them except where stated.
- *   steps_per_launch  0 auto / 1 / 2 (2D also 4 with the row-streaming kernel, 1D also 4, 8) : applications per launch
- *                     in lora_plan_run (temporal fusion)
+ *   steps_per_launch  0 auto / 1 / 2 (2D also 4 with the row-streaming kernel, 3D fp64 also 3 with the plane-streaming
+ *                     kernel, 1D also 4, 8) : applications per launch in lora_plan_run (temporal fusion)
  *   rows_per_thread, panel_width, nt_store, fused_rows, persistent      2D tile shape / block->tile map / stores
  *   lowrank_valu      -1 auto / 0 off / 1 on / 2, 3 (plain / symmetric pyramid form) / 4 (rank-1 + correction instead of the
  *                     nested-profile form) : structured evaluation of the taps inside the fused 2D kernels (summation
  *                     order changes: identical while values are exact integers, ~1 ulp afterwards)
  *   z_chunk, fused_z_chunk             3D output planes per workgroup (single-sweep / fused kernels; 0 = auto)
+ *   stream3           3D fp64 fused launches: 1 = plane-streaming kernel (kernels_3d_planes.hip: LDS-DMA plane ring, three
+ *                     applications per launch for the 7-point star, two for the box), 0 = the two-application tile kernel;
+ *                     stream3_waves (8 / 7 / 6 waves per workgroup, one per CU, or 4, two per CU), stream3_slots (input
+ *                     planes in the ring, 0 = as many as fit), stream3_pipe (1 = one barrier per plane, two buffers
+ *                     per published level; always on for two applications)
  *   separable         -1 auto / 0     bf16: exactly separable taps as x/y/z passes (changes the fp32 summation
  *                     order; the oracle restates both orders, see lora_separable_3x3x3)
  *   cols_per_lane, lds_dma, fused_pipeline                              bf16 kernel variants
@@ -216,9 +221,11 @@ int lora_plan_region_granularity(const lora_plan *plan);
 int lora_plan_step2(lora_plan *plan, const void *d_in, void *d_out, void *stream);
 int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream);
 /* The plan's resolved "steps_per_launch" applications in ONE launch: 1 = lora_plan_step, 2 = lora_plan_step2 (2D / 3D),
- * 2 / 4 / 8 in 1D (intermediate levels in LDS; halo cells of odd intermediate levels are 0, of even ones the source
+ * 4 in 2D, 3 in 3D fp64, 2 / 4 / 8 in 1D (intermediate levels in LDS; halo cells of odd intermediate levels are 0, of even ones the source
  * buffer's halo -- the state the step-by-step driver would leave).  d_in must be an even time level.
- * lora_plan_run uses an even number of these and finishes with single sweeps. */
+ * lora_plan_run uses an even number of these and finishes with single sweeps; three-application 3D launches have an
+ * odd count and run on the reference's alternating buffer state instead (launch k reads buffer k mod 2, whose halo
+ * is the caller's for even k and zero for odd k), any number of them. */
 int lora_plan_stepk(lora_plan *plan, const void *d_in, void *d_out, void *stream);
 int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream);
 /* Halo cells of a padded device array (every cell outside the interior, any shape / dtype of the plan): copied from

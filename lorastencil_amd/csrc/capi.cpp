@@ -295,7 +295,7 @@ void plan_refresh(Plan &p) {
         // two applications per launch (kernels_3d_fused.hip): fp64 tiled path; default, as in 2D (star3d1r 512^3
         // 499 vs 288 GStencils/s, box3d1r 768^3 523 vs 300)
         p.steps_per_launch = (!p.generic && p.steps_per_launch_req != 1) ? 2 : 1;
-        // fp64: THREE applications per launch in the plane-streaming kernel (kernels_3d_stream.hip) -- the grid is read
+        // fp64: THREE applications per launch in the plane-streaming kernel (kernels_3d_planes.hip) -- the grid is read
         // and written once per three sweeps.  An odd count needs no halo copies: launch k starts at global step 3 k and
         // runs on the reference's own buffer state (lora_plan_run)
         const bool stream3 = p.dtype != LORA_BF16 && !p.generic && p.stream3 != 0;
@@ -727,7 +727,7 @@ const char *lora_plan_kernel_signature(const lora_plan *plan) {
                       p.panel_width);
     else if (k == "stencil2d_mfma_kernel")
         std::snprintf(buf, sizeof buf, "rank=%d,panel=%d", p.lowrank.rank, p.panel_width);
-    else if (k == "stencil3d_stream_kernel")
+    else if (k == "stencil3d_planes_kernel")
 {
         const int K = p.steps_per_launch, pipe = (K == 2 || p.stream3_pipe) ? 1 : 0;
         const int nw = lora::stream3_waves(K, pipe, p.stream3_waves);

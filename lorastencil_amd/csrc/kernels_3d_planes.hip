@@ -1,4 +1,4 @@
-// kernels_3d_stream.hip -- K = 2 or 3 applications of a 3D radius-1 stencil per launch (fp64): plane streaming.
+// kernels_3d_planes.hip -- K = 2 or 3 applications of a 3D radius-1 stencil per launch (fp64): plane streaming.
 //
 // kernels_3d_fused.hip (two applications, 30 x 60 output tiles, z-chunks of 16 planes, one register-staged plane of
 // prefetch) moves 1.24 x its compulsory HBM bytes at ~4.9 TB/s -- it is HBM-bound on the bytes it really moves
@@ -125,7 +125,7 @@ struct Geo {
 };
 
 template <int TAPSET, int K, int NW, int NS, bool PIPE, bool DIRICHLET>
-__global__ __launch_bounds__(NW * 64, 2) void stencil3d_stream_kernel(const ArgsS3 a, const Taps27 W) {
+__global__ __launch_bounds__(NW * 64, 2) void stencil3d_planes_kernel(const ArgsS3 a, const Taps27 W) {
     constexpr int STRIPS = 2 * NW;
     constexpr int MH = STRIPS * kRY;              // level-1 rows
     constexpr int IH = MH + 2;                    // input rows
@@ -490,8 +490,8 @@ hipError_t launch_stream3(const Plan &p, const double *in, double *out, const do
 #endif
         return hipGetLastError();
     };
-    if (p.boundary == LORA_BC_DIRICHLET) return go(stencil3d_stream_kernel<TAPSET, K, NW, NS, PIPE, true>);
-    return go(stencil3d_stream_kernel<TAPSET, K, NW, NS, PIPE, false>);
+    if (p.boundary == LORA_BC_DIRICHLET) return go(stencil3d_planes_kernel<TAPSET, K, NW, NS, PIPE, true>);
+    return go(stencil3d_planes_kernel<TAPSET, K, NW, NS, PIPE, false>);
 }
 
 }  // namespace
@@ -547,6 +547,6 @@ hipError_t launch_3d_stream(const Plan &p, int K, const double *in, double *out,
     return hipErrorInvalidValue;
 }
 
-const char *kernel_name_3d_stream(const Plan &) { return "stencil3d_stream_kernel"; }
+const char *kernel_name_3d_stream(const Plan &) { return "stencil3d_planes_kernel"; }
 
 }  // namespace lora

@@ -1,5 +1,5 @@
 // planes_3d.h -- the per-plane tap evaluation shared by the fp64 3D kernels that fuse applications in time
-// (kernels_3d_fused.hip, kernels_3d_stream.hip): a plane of level l - 1 is read once from LDS and scattered, weighted
+// (kernels_3d_fused.hip, kernels_3d_planes.hip): a plane of level l - 1 is read once from LDS and scattered, weighted
 // per dz / dy / dx, into three rotating accumulator sets of level l (the planes above, at and below it).  The order in
 // which a cell receives its taps -- dz outermost, then dy, then dx -- is the single-sweep kernel's (kernels_3d.hip), so
 // any chain of fused levels is bit-identical to the same number of single sweeps.

@@ -445,7 +445,7 @@ FUSED_3D = {
 @pytest.mark.parametrize("dims", [(40, 60, 128), (9, 31, 62), (37, 29, 190), (3, 5, 2), (70, 64, 64)])
 @pytest.mark.parametrize("cfg", list(FUSED_3D))
 def test_3d_fused_launches_equal_step_by_step(L, O, shape, dims, cfg):
-    """kernels_3d_stream.hip (three or two applications per launch, inner time levels in LDS) and kernels_3d_fused.hip
+    """kernels_3d_planes.hip (three or two applications per launch, inner time levels in LDS) and kernels_3d_fused.hip
     (two).  Same taps in the same order at every level, so the whole padded buffer (interior and the halo state the
     step-by-step driver leaves behind) equals the oracle bit for bit while values are exact integers, and to rounding
     afterwards.  Three-application launches run on the reference's alternating buffer state: any step count, odd
@@ -459,7 +459,7 @@ def test_3d_fused_launches_equal_step_by_step(L, O, shape, dims, cfg):
         assert plan.get_option("steps_per_launch") == (3 if shape == "star3d1r" else 2)
     if cfg != "default":
         assert plan.get_option("steps_per_launch") == opts["steps_per_launch"]
-    assert plan.kernel_name == ("stencil3d_fused2_kernel" if cfg == "tile2" else "stencil3d_stream_kernel")
+    assert plan.kernel_name == ("stencil3d_fused2_kernel" if cfg == "tile2" else "stencil3d_planes_kernel")
     for t in (3, 4, 5, 6, 7, 9):
         exp = O.run(shape, a, t)
         for zc in (0, 1, 3, 8):
@@ -502,7 +502,7 @@ def test_3d_three_step_launches_real_weights_both_boundaries(L, O, shape, bounda
         for opts in ({"steps_per_launch": 3}, {"steps_per_launch": 3, "stream3_waves": 4, "fused_z_chunk": 5},
                      {"steps_per_launch": 3, "stream3_pipe": 1}):
             got, plan = run(t, opts)
-            assert plan.kernel_name == "stencil3d_stream_kernel" and plan.get_option("steps_per_launch") == 3
+            assert plan.kernel_name == "stencil3d_planes_kernel" and plan.get_option("steps_per_launch") == 3
             assert np.array_equal(got, single), (shape, boundary, t, opts)
         exp = O.run_bc(shape, a, t, boundary, weights=w) if boundary != "reference" else O.run(shape, a, t, weights=w)
         assert rel_err(single, exp) < 1e-13
@@ -566,7 +566,7 @@ def test_3d_fused_step2_regions_and_real_weights(L, O):
             w /= np.abs(w).sum()
         exp = O.run(shape, a, 2, weights=w)  # buffer 0 after two sweeps: interior + the input halo
         plan = L.Plan(shape, dims).set_weights(w).set_option("steps_per_launch", 2)
-        assert plan.kernel_name == "stencil3d_stream_kernel"
+        assert plan.kernel_name == "stencil3d_planes_kernel"
         src = torch.from_numpy(a).cuda()
         dst = torch.from_numpy(a).cuda()
         dst[1:-1, 2:-2, 4:-4] = -1.0
