@@ -183,7 +183,8 @@ int lora_set_default_normalize(int on);
  *                     applications per launch for the 7-point star, two for the box), 0 = the two-application tile kernel;
  *                     stream3_waves (8 / 7 / 6 waves per workgroup, one per CU, or 4, two per CU), stream3_slots (input
  *                     planes in the ring, 0 = as many as fit), stream3_pipe (1 = one barrier per plane, two buffers
- *                     per published level; always on for two applications)
+ *                     per published level; always on for two applications), stream3_async (1 = no workgroup barriers:
+ *                     neighbour-wave counters in LDS; bit-identical, measured slower, off)
  *   separable         -1 auto / 0     bf16: exactly separable taps as x/y/z passes (changes the fp32 summation
  *                     order; the oracle restates both orders, see lora_separable_3x3x3)
  *   cols_per_lane, lds_dma, fused_pipeline                              bf16 kernel variants

@@ -576,6 +576,8 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "stream3_waves")) {
         if (value != 4 && value != 6 && value != 7 && value != 8) return LORA_EINVAL;
         p.stream3_waves = value;
+    } else if (!std::strcmp(key, "stream3_async")) {
+        p.stream3_async = value ? 1 : 0;
     } else if (!std::strcmp(key, "stream3_pipe")) {
         p.stream3_pipe = value ? 1 : 0;
     } else if (!std::strcmp(key, "stream3_slots")) {
@@ -664,6 +666,8 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.stream3_slots;
     else if (!std::strcmp(key, "stream3_pipe"))
         *value = p.stream3_pipe;
+    else if (!std::strcmp(key, "stream3_async"))
+        *value = p.stream3_async;
     else if (!std::strcmp(key, "stream_rows"))
         *value = p.stream_rows;
     else if (!std::strcmp(key, "stream_depth"))
@@ -731,8 +735,12 @@ const char *lora_plan_kernel_signature(const lora_plan *plan) {
 {
         const int K = p.steps_per_launch, pipe = (K == 2 || p.stream3_pipe) ? 1 : 0;
         const int nw = lora::stream3_waves(K, pipe, p.stream3_waves);
-        std::snprintf(buf, sizeof buf, "taps=%d,k=%d,waves=%d,slots=%d,pipe=%d,fzc=%d,bc=%d", p.tapset, K, nw,
-                      lora::stream3_slots(K, nw, pipe, p.stream3_slots), pipe, p.fused_z_chunk, p.boundary);
+        if (p.stream3_async && (p.stream3_waves == 8 || p.stream3_waves == 4))
+            std::snprintf(buf, sizeof buf, "taps=%d,k=%d,waves=%d,async=1,fzc=%d,bc=%d", p.tapset, K, p.stream3_waves,
+                          p.fused_z_chunk, p.boundary);
+        else
+            std::snprintf(buf, sizeof buf, "taps=%d,k=%d,waves=%d,slots=%d,pipe=%d,fzc=%d,bc=%d", p.tapset, K, nw,
+                          lora::stream3_slots(K, nw, pipe, p.stream3_slots), pipe, p.fused_z_chunk, p.boundary);
     }
     else if (p.ndim == 3 && p.dtype == LORA_BF16)
         std::snprintf(buf, sizeof buf, "taps=%d,zc=%d,fzc=%d,cpl=%d,dma=%d,pipe=%d,bc=%d", p.tapset, p.z_chunk,

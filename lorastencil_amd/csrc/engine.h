@@ -78,6 +78,7 @@ struct Plan {
     int stream3 = 1;          // 3D fp64 fused: plane-streaming kernel (kernels_3d_planes.hip: 2 or 3 applications per launch) or the tile kernel (0, 2 applications)
     int stream3_waves = 8;    // 3D plane-streaming kernel: waves per workgroup: 8 / 7 / 6 (one workgroup per CU) or 4 (two); output tiles of 8 x waves - 2 (K - 1) rows x 60 columns
     int stream3_pipe = 0;     // 3D plane-streaming kernel: 1 = every level consumes what was published one step earlier (one barrier per step, two buffers per level)
+    int stream3_async = 0;    // 3D plane-streaming kernel: 1 = no workgroup barriers (neighbour-wave counters in LDS, private input rings)
     int stream3_slots = 0;    // 3D plane-streaming kernel: input plane slots of the LDS ring (0 = as many as fit)
     int fused_z_chunk = 0;    // 3D fused: output planes per workgroup (0 = auto: 32, shorter on small grids)
     int steps_per_launch_req = 0;  // 0 = auto, 1, 2 (2D / 3D), 4 (2D row-streaming kernel), 2 / 4 / 8 (1D)

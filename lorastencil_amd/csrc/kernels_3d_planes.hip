@@ -389,6 +389,220 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_planes_kernel(const Args
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same computation WITHOUT workgroup barriers ("async", plan option stream3_async).
+//
+// With one workgroup per CU at two waves per SIMD, K barriers per plane put the eight waves in lockstep: all read their
+// windows, then all compute, then all publish -- the LDS and the vector pipe are used one after the other.
+// But a wave depends on very little of what the others do:
+//   * its level-(l+1) window reads rows 8 w .. 8 w + 9 of level l: its own eight rows and the first TWO rows its lower
+//     neighbour (wave w + 1) publishes;
+//   * it may overwrite its own rows of level l for the next plane once its UPPER neighbour (wave w - 1) has read them.
+// So every wave gets (a) a private ring of input plane pieces -- the ten input rows it reads, loaded by itself with
+// LDS-DMA, two of them also by its neighbour: no cross-wave dependence on input at all, its own vmcnt is enough -- and
+// (b) two counters per published level in LDS: pub[l][w] = planes of level l wave w has published, rd[l][w] = planes of
+// level l it has finished reading.  Wave w waits for pub[l][w + 1] before it reads level l and for rd[l][w - 1] before
+// it overwrites it.  A wave's LDS operations execute in order, so "data, then counter" needs no fence; waits go from
+// wave w to w + 1 (same plane) or to w - 1 (previous plane), so they cannot form a cycle; and every wait loop is
+// bounded -- a lost update would end in wrong numbers (caught by the parity tests), never in a hung GPU.
+// The levels are the barrier version's, instruction for instruction: results are bit-identical.
+__device__ __forceinline__ void flag_set(int *f, int v) {
+    asm volatile("" ::: "memory");
+    *reinterpret_cast<volatile int *>(f) = v;
+}
+
+__device__ __forceinline__ void flag_wait(const int *f, int target) {
+    for (int spin = 0; spin < (1 << 18); ++spin) {  // ~20 ms: never reached unless a counter update is lost
+        const int v = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const volatile int *>(f));
+        if (v >= target) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
+template <int TAPSET, int K, int NW, bool DIRICHLET>
+__global__ __launch_bounds__(NW * 64, 2) void stencil3d_planes_async_kernel(const ArgsS3 a, const Taps27 W) {
+    constexpr int NS = 2;                         // input plane slots per wave
+    constexpr int STRIPS = 2 * NW;
+    constexpr int MH = STRIPS * kRY;              // level-1 rows
+    constexpr int OH = MH - 2 * (K - 1);          // output rows
+    constexpr int AROWS = 2 * kRY + 2;            // input rows one wave reads
+    constexpr int APIECE = AROWS * kPieces;       // 340 pieces of 16 bytes
+    constexpr int AINST = (APIECE + 63) / 64;     // 6 LDS-DMA instructions per wave and plane
+    constexpr int ASLOT = APIECE * 2;             // doubles per wave slot
+    constexpr int TILE = MH * kRowW;
+    static_assert(K == 2 || K == 3, "two or three applications per launch");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *const A = reinterpret_cast<double *>(smem);          // NW x NS private slots
+    double *const B = A + NW * NS * ASLOT;                       // levels 1 .. K - 1, then 2 pad rows
+    int *const flags = reinterpret_cast<int *>(B + (K - 1) * TILE + 2 * kRowW);  // pub[K - 1][NW], rd[K - 1][NW]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int sid = wv * 2 + lane / kLanesX;
+    const int cl = lane % kLanesX;
+
+    const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int per_chunk = a.tiles_x * a.tiles_y;
+    const int chunk = lin / per_chunk;
+    const int rem = lin - chunk * per_chunk;
+    const int ty = rem / a.tiles_x;
+    const int tx = rem - ty * a.tiles_x;
+    const int k0 = a.z_begin + chunk * a.zc;
+    const int I = ty * OH;
+    const int J = tx * kOutW;
+    const int zc = min(a.zc, a.z_end - k0);
+    const int nplanes = zc + 2 * K;
+
+    if (tid < 2 * (K - 1) * NW) flags[tid] = 0;
+    __syncthreads();  // the only workgroup barrier: counters start at 0
+    int *const pub_mine = flags + wv;             // + (l - 1) * NW
+    int *const rd_mine = flags + (K - 1) * NW + wv;
+
+    // this wave's input rows: tile rows 8 w .. 8 w + 9 <-> padded rows I - K + 2 + 8 w + r
+    int goff[AINST];
+#pragma unroll
+    for (int t = 0; t < AINST; ++t) {
+        const int g = min(t * 64, APIECE - 64) + lane;
+        const int r = g / kPieces;
+        const int c = g - r * kPieces;
+        const int gr = min(max(I - K + 2 + 2 * kRY * wv + r, 0), a.m + 3);
+        const int gc = min(J + 2 * c, a.n + 6);
+        goff[t] = gr * a.ld + gc;
+    }
+    double *const Aw = A + wv * NS * ASLOT;
+    auto issue = [&](int p) {
+        const double *src = a.in + (long) min(max(k0 - K + 1 + p, 0), a.h + 1) * a.plane;
+        double *slot = Aw + (p % NS) * ASLOT;
+#pragma unroll
+        for (int t = 0; t < AINST; ++t)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (src + goff[t]),
+                                             (__attribute__((address_space(3))) void *) (slot + 2 * min(t * 64, APIECE - 64)), 16, 0,
+                                             0);
+    };
+
+    double x0[K][3][kRY], x1[K][3][kRY];
+#pragma unroll
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int r = 0; r < kRY; ++r) x0[l][s][r] = x1[l][s][r] = 0.0;
+
+    const int strip_off = (sid * kRY) * kRowW + 2 * cl;                    // in a level tile
+    const int strip_offA = ((lane / kLanesX) * kRY) * kRowW + 2 * cl;      // in this wave's input slot
+    const bool lvl_halo[3] = {false, DIRICHLET || ((a.parity + 1) & 1) == 0, DIRICHLET || ((a.parity + 2) & 1) == 0};
+    const int colo = J - 4 + Geo<K>::base(K) + 2 * cl;
+    const bool colo_ok = cl >= Geo<K>::out_lane0 && cl < Geo<K>::out_lane0 + kOutW / 2 && colo < a.n;
+    const int rowo = I + sid * kRY;
+    double *const out_col = a.out + (long) (rowo + 2) * a.ld + (colo + 4);
+
+#pragma unroll
+    for (int p = 0; p < NS; ++p) issue(p);
+
+    auto level = [&](int p, auto level_tag, auto phase_tag) {
+        constexpr int L = decltype(level_tag)::value;
+        constexpr int PH = decltype(phase_tag)::value;  // (p - (L - 1)) mod 3
+        if constexpr (L == 1) {
+            wait_loads<(NS - 1) * AINST>();  // this wave's pieces of plane p have landed (younger loads: plane p + 1)
+        } else {
+            // level L - 1 of this plane step: the lower neighbour's first two rows must be there
+            if (wv + 1 < NW) flag_wait(pub_mine + (L - 2) * NW + 1, p + 1);
+        }
+        const double *strip = L == 1 ? Aw + (p % NS) * ASLOT + strip_offA : B + (L - 2) * TILE + strip_off;
+        double win[kRY + 2][6];
+#pragma unroll
+        for (int j = 0; j < kRY + 2; ++j) read_window<TAPSET>(strip + j * kRowW, j >= 1 && j <= kRY, win[j]);
+#pragma unroll
+        for (int j = 1; j <= kRY; ++j) asm volatile("" ::"v"(win[j][0]), "v"(win[j][5]));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the window is in registers
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (L == 1) {
+            issue(p + NS);  // the slot is free again
+        } else {
+            flag_set(rd_mine + (L - 2) * NW, p + 1);  // the upper neighbour's rows of level L - 1 may be overwritten
+        }
+#pragma unroll
+        for (int j = 0; j < kRY + 2; ++j) scatter_row<TAPSET, kRY, PH, true>(x0[L - 1], x1[L - 1], win[j], j, W);
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int r = 0; r < kRY; ++r) asm volatile("" : "+v"(x0[L - 1][s][r]), "+v"(x1[L - 1][s][r]));
+        constexpr int s = (PH + 1) % 3;
+        if constexpr (L < K) {
+            const int z = k0 - K + p - (L - 1) - 1;
+            const int row = I - K + L + sid * kRY;
+            const int col = J - 4 + Geo<K>::base(L) + 2 * cl;
+            const bool zc_in = z >= 0 && z < a.h && col >= 0 && col < a.n;
+            double *dst = B + (L - 1) * TILE + strip_off + Geo<K>::pub(L);
+            // the upper neighbour has read what the previous plane step left in this wave's first two rows
+            if (wv > 0) flag_wait(rd_mine + (L - 1) * NW - 1, p);
+            bool rim = false;
+#pragma unroll
+            for (int r = 0; r < kRY; ++r) rim |= !(zc_in && row + r >= 0 && row + r < a.m);
+            if (__builtin_amdgcn_ballot_w64(rim) != 0) {
+#pragma unroll
+                for (int r = 0; r < kRY; ++r) {
+                    const bool in = zc_in && row + r >= 0 && row + r < a.m;
+                    d2 v;
+                    v.x = in ? x0[L - 1][s][r] : 0.0;
+                    v.y = in ? x1[L - 1][s][r] : 0.0;
+                    if (!in && lvl_halo[L]) {
+                        const int pz = z + 1, pr = row + r + 2, pc = col + 4;
+                        if (pz >= 0 && pz <= a.h + 1 && pr >= 0 && pr <= a.m + 3 && pc >= 0 && pc + 1 <= a.n + 7)
+                            v = load_halo_pair(a.halo_src + (long) pz * a.plane + (long) pr * a.ld + pc);
+                    }
+                    *reinterpret_cast<d2 *>(dst + r * kRowW) = v;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < kRY; ++r) {
+                    d2 v;
+                    v.x = x0[L - 1][s][r];
+                    v.y = x1[L - 1][s][r];
+                    *reinterpret_cast<d2 *>(dst + r * kRowW) = v;
+                }
+            }
+            flag_set(pub_mine + (L - 1) * NW, p + 1);  // after the rows, in this wave's LDS order
+        } else {
+            const int o = p - 2 * K;
+            if (o >= 0 && o < zc && colo_ok) {
+                double *dst = out_col + (long) (k0 + o + 1) * a.plane;
+#pragma unroll
+                for (int r = 0; r < kRY; ++r) {
+                    if (sid * kRY + r < OH && rowo + r < a.m) {
+                        d2 v;
+                        v.x = x0[L - 1][s][r];
+                        v.y = x1[L - 1][s][r];
+                        *reinterpret_cast<d2 *>(dst + (long) r * a.ld) = v;
+                    }
+                }
+            }
+        }
+    };
+
+    auto step = [&](int p, auto phase_tag) {
+        constexpr int PH0 = decltype(phase_tag)::value;
+        level(p, std::integral_constant<int, 1>{}, std::integral_constant<int, PH0>{});
+        level(p, std::integral_constant<int, 2>{}, std::integral_constant<int, (PH0 + 2) % 3>{});
+        if constexpr (K == 3) level(p, std::integral_constant<int, 3>{}, std::integral_constant<int, (PH0 + 1) % 3>{});
+    };
+    for (int p = 0; p < nplanes; p += 3) {
+        step(p, std::integral_constant<int, 0>{});
+        if (p + 1 < nplanes) step(p + 1, std::integral_constant<int, 1>{});
+        if (p + 2 < nplanes) step(p + 2, std::integral_constant<int, 2>{});
+    }
+    wait_loads<0>();  // no LDS-DMA may be in flight when the wave ends
+}
+
+template <int K, int NW>
+constexpr size_t stream3_async_lds_bytes() {
+    return (size_t) (NW * 2 * (2 * kRY + 2) * kRowW + (K - 1) * 2 * NW * kRY * kRowW + 2 * kRowW) * sizeof(double) +
+           2 * (K - 1) * NW * sizeof(int);
+}
+
 template <int K, int NW, int NS, bool PIPE>
 constexpr size_t stream3_lds_bytes() {
     constexpr int MH = 2 * NW * kRY;
@@ -460,7 +674,8 @@ hipError_t launch_stream3(const Plan &p, const double *in, double *out, const do
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
     Taps27 w;
     for (int k = 0; k < 27; ++k) w.w[k] = p.w[k];
-    constexpr size_t lds = stream3_lds_bytes<K, NW, NS, PIPE>();
+    constexpr bool ASYNC = NS == 0;  // NS = 0 selects the barrier-free kernel
+    constexpr size_t lds = ASYNC ? stream3_async_lds_bytes<K, NW>() : stream3_lds_bytes<K, NW, NS ? NS : 2, PIPE>();
     static_assert(lds <= (NW == 4 ? 80 : 160) * 1024, "LDS budget");
     auto go = [&](auto kernel) -> hipError_t {
         // per instantiation and device: more than 64 KiB of dynamic LDS has to be asked for once
@@ -490,8 +705,13 @@ hipError_t launch_stream3(const Plan &p, const double *in, double *out, const do
 #endif
         return hipGetLastError();
     };
-    if (p.boundary == LORA_BC_DIRICHLET) return go(stencil3d_planes_kernel<TAPSET, K, NW, NS, PIPE, true>);
-    return go(stencil3d_planes_kernel<TAPSET, K, NW, NS, PIPE, false>);
+    if constexpr (ASYNC) {
+        if (p.boundary == LORA_BC_DIRICHLET) return go(stencil3d_planes_async_kernel<TAPSET, K, NW, true>);
+        return go(stencil3d_planes_async_kernel<TAPSET, K, NW, false>);
+    } else {
+        if (p.boundary == LORA_BC_DIRICHLET) return go(stencil3d_planes_kernel<TAPSET, K, NW, NS, PIPE, true>);
+        return go(stencil3d_planes_kernel<TAPSET, K, NW, NS, PIPE, false>);
+    }
 }
 
 }  // namespace
@@ -529,6 +749,20 @@ hipError_t launch_3d_stream(const Plan &p, int K, const double *in, double *out,
         return p.tapset == TAPS3D_STAR                                                                                \
                    ? launch_stream3<TAPS3D_STAR, KK, WW, SS, PP != 0>(p, in, out, halo_src, parity, begin, end, s)    \
                    : launch_stream3<TAPS3D_BOX, KK, WW, SS, PP != 0>(p, in, out, halo_src, parity, begin, end, s);
+    if (p.stream3_async && (nw == 8 || nw == 4)) {  // barrier-free form: 8 waves (one workgroup per CU) or 4 (two)
+        const bool star = p.tapset == TAPS3D_STAR;
+        if (K == 3 && nw == 8)
+            return star ? launch_stream3<TAPS3D_STAR, 3, 8, 0, false>(p, in, out, halo_src, parity, begin, end, s)
+                        : launch_stream3<TAPS3D_BOX, 3, 8, 0, false>(p, in, out, halo_src, parity, begin, end, s);
+        if (K == 3)
+            return star ? launch_stream3<TAPS3D_STAR, 3, 4, 0, false>(p, in, out, halo_src, parity, begin, end, s)
+                        : launch_stream3<TAPS3D_BOX, 3, 4, 0, false>(p, in, out, halo_src, parity, begin, end, s);
+        if (nw == 8)
+            return star ? launch_stream3<TAPS3D_STAR, 2, 8, 0, false>(p, in, out, halo_src, parity, begin, end, s)
+                        : launch_stream3<TAPS3D_BOX, 2, 8, 0, false>(p, in, out, halo_src, parity, begin, end, s);
+        return star ? launch_stream3<TAPS3D_STAR, 2, 4, 0, false>(p, in, out, halo_src, parity, begin, end, s)
+                    : launch_stream3<TAPS3D_BOX, 2, 4, 0, false>(p, in, out, halo_src, parity, begin, end, s);
+    }
     LORA_S3(3, 8, 2, 0)
     LORA_S3(3, 7, 3, 0)
     LORA_S3(3, 7, 2, 0)
@@ -541,6 +775,7 @@ hipError_t launch_3d_stream(const Plan &p, int K, const double *in, double *out,
     LORA_S3(2, 7, 3, 1)
     LORA_S3(2, 7, 2, 1)
     LORA_S3(2, 6, 4, 1)
+    LORA_S3(2, 6, 3, 1)
     LORA_S3(2, 6, 2, 1)
     LORA_S3(2, 4, 2, 1)
 #undef LORA_S3

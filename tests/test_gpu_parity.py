@@ -438,6 +438,9 @@ FUSED_3D = {
     "stream2_w4": {"steps_per_launch": 2, "stream3_waves": 4},
     "stream2_w7pipe": {"steps_per_launch": 2, "stream3_waves": 7, "stream3_pipe": 1},
     "tile2": {"stream3": 0, "steps_per_launch": 2},
+    "async3": {"steps_per_launch": 3, "stream3_async": 1},
+    "async3_w4": {"steps_per_launch": 3, "stream3_async": 1, "stream3_waves": 4},
+    "async2": {"steps_per_launch": 2, "stream3_async": 1},
 }
 
 
@@ -549,7 +552,9 @@ def test_3d_stream_kernel_at_scale_equals_single_sweeps(L, shape, dims):
     ref = run({"steps_per_launch": 1}, 6)
     for k in (3, 2):
         for wv in (8, 7, 6, 4):
-            for extra in ({}, {"stream3_pipe": 1}):
+            for extra in ({}, {"stream3_pipe": 1}, {"stream3_async": 1}):
+                if "stream3_async" in extra and wv not in (8, 4):
+                    continue
                 got = run(dict({"steps_per_launch": k, "stream3_waves": wv}, **extra), 6)
                 assert torch.equal(got, ref), (shape, k, wv, extra)
 
