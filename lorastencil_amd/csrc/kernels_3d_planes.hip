@@ -217,6 +217,21 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_planes_kernel(const Args
     const bool colo_ok = cl >= Geo<K>::out_lane0 && cl < Geo<K>::out_lane0 + kOutW / 2 && colo < a.n;
     const int rowo = I + sid * kRY;
     double *const out_col = a.out + (long) (rowo + 2) * a.ld + (colo + 4);
+    // Loop-invariant, wave-uniform shortcuts (a wave issues one instruction every few cycles, and at two waves per SIMD
+    // the length of its instruction stream is what bounds this kernel: the per-lane range checks below cost more
+    // scalar instructions per plane than the taps cost vector ones).  xy_all[l]: every cell this wave owns at level l
+    // lies inside the interior in x and y -- then a plane inside the z range is published without any per-lane check;
+    // store_all: every lane stores all of its four output rows.
+    bool xy_all[K];
+#pragma unroll
+    for (int l = 1; l < K; ++l) {
+        const int row = I - K + l + sid * kRY;
+        const int col = J - 4 + Geo<K>::base(l) + 2 * cl;
+        const bool lane_in = col >= 0 && col < a.n && row >= 0 && row + kRY - 1 < a.m;
+        xy_all[l] = __builtin_amdgcn_ballot_w64(!lane_in) == 0;
+    }
+    const bool store_all =
+        __builtin_amdgcn_ballot_w64(!(colo_ok && sid * kRY + kRY - 1 < OH && rowo + kRY - 1 < a.m)) == 0;
 
 #pragma unroll
     for (int p = 0; p < NS; ++p) issue(p);
@@ -300,10 +315,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_planes_kernel(const Args
             // the few waves on the grid's rim: the common path publishes its sums as they are.  (The compiler waits
             // for vmcnt(0) before it uses a loaded register; on the common path that wait drained the whole prefetch
             // stream -- LDS-DMA loads and output stores -- at every publish.)
-            bool rim = false;
-#pragma unroll
-            for (int r = 0; r < kRY; ++r) rim |= !(zc_in && row + r >= 0 && row + r < a.m);
-            if (__builtin_amdgcn_ballot_w64(rim) != 0) {
+            if (!(z >= 0 && z < a.h && xy_all[L])) {
 #pragma unroll
                 for (int r = 0; r < kRY; ++r) {
                     const bool in = zc_in && row + r >= 0 && row + r < a.m;
@@ -329,15 +341,25 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_planes_kernel(const Args
             }
         } else {
             const int o = p - K - LAG * (K - 1) - 1;
-            if (o >= 0 && o < zc && colo_ok && !(LORA_ABLATE(a) & 4)) {
+            if (o >= 0 && o < zc && !(LORA_ABLATE(a) & 4)) {
                 double *dst = out_col + (long) (k0 + o + 1) * a.plane;
+                if (store_all) {
 #pragma unroll
-                for (int r = 0; r < kRY; ++r) {
-                    if (sid * kRY + r < OH && rowo + r < a.m) {
+                    for (int r = 0; r < kRY; ++r) {
                         d2 v;
                         v.x = x0[L - 1][s][r];
                         v.y = x1[L - 1][s][r];
                         *reinterpret_cast<d2 *>(dst + (long) r * a.ld) = v;
+                    }
+                } else if (colo_ok) {
+#pragma unroll
+                    for (int r = 0; r < kRY; ++r) {
+                        if (sid * kRY + r < OH && rowo + r < a.m) {
+                            d2 v;
+                            v.x = x0[L - 1][s][r];
+                            v.y = x1[L - 1][s][r];
+                            *reinterpret_cast<d2 *>(dst + (long) r * a.ld) = v;
+                        }
                     }
                 }
             }
