@@ -372,6 +372,9 @@ def main():
         spl = plan.get_option("steps_per_launch")
         if prof.fused_launches > 0:
             launches, apps, launch_s = prof.fused_launches, prof.apps_per_fused_launch, prof.fused_ms / 1e3 / prof.fused_launches
+            if apps != spl:  # 1D: lora_plan_run fuses 16 / 32 sweeps per launch on long runs (the plan's own depth is 8)
+                signature = signature.replace(f"k={spl}", f"k={apps}")
+                spl = apps
         else:
             launches, apps, launch_s = max(prof.single_launches, 1), 1, prof.single_ms / 1e3 / max(prof.single_launches, 1)
             single = L.Plan(shape, dims, dtype=args.dtype).set_weights(weights).set_option("steps_per_launch", 1)

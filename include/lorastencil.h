@@ -173,7 +173,9 @@ int lora_set_default_boundary(int boundary);
 int lora_set_default_normalize(int on);
 /* Integer options.  Results never depend on them except where stated.
  *   steps_per_launch  0 auto / 1 / 2 (2D also 4 with the row-streaming kernel, 3D fp64 also 3 with the plane-streaming
- *                     kernel, 1D also 4, 8) : applications per launch in lora_plan_run (temporal fusion)
+ *                     kernel, 1D also 4, 8, 16, 32) : applications per launch in lora_plan_run (temporal fusion).  1D auto:
+ *                     the plan's own depth is 8 (lora_plan_stepk, slabs); lora_plan_run uses 16 from 32 sweeps on and
+ *                     32 from 64 on
  *   rows_per_thread, panel_width, nt_store, fused_rows, persistent      2D tile shape / block->tile map / stores
  *   lowrank_valu      -1 auto / 0 off / 1 on / 2, 3 (plain / symmetric pyramid form) / 4 (rank-1 + correction instead of the
  *                     nested-profile form) : structured evaluation of the taps inside the fused 2D kernels (summation

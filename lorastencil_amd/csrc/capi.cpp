@@ -622,7 +622,8 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         p.fused_rows_req = value;
     } else if (!std::strcmp(key, "steps_per_launch")) {
         const bool three = value == 3 && p.ndim == 3 && p.dtype != LORA_BF16;  // 3D fp64 plane-streaming kernel
-        if (value < 0 || value > 8 || ((value & (value - 1)) && !three)) return LORA_EINVAL;  // 0 (auto), 1, 2, 4, 8
+        if (value < 0 || value > 32 || ((value & (value - 1)) && !three)) return LORA_EINVAL;  // 0 (auto), 1, 2, 4, 8, 16, 32
+        if (value > 8 && p.ndim != 1) return LORA_EUNSUPPORTED;  // 16 and 32 exist in 1D only
         const bool fusable = (p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && (!p.generic || p.stream2)) ||
                              (p.ndim == 3 && !p.generic) || p.ndim == 1;
         if (value >= 2 && !fusable) return LORA_EUNSUPPORTED;
@@ -1041,9 +1042,24 @@ static void drop_graph(lora_plan *plan) {
     plan->graph_times = -1;
 }
 
+// 1D runs with the automatic launch depth fuse more applications per launch the longer the run is: 8 is the plan's
+// own depth (what lora_plan_stepk and the slab drivers use), 16 / 32 pay from 32 / 64 sweeps on (2^20 points: 840 ->
+// 999 -> 1066 GStencils/s per launch, 2^28: 1600 -> 1915 -> 1987; tools/k1d.sh) while short runs keep enough fused
+// launches.  Scoped to one lora_plan_run / lora_plan_run_profiled call.
+struct RunDepth1D {
+    Plan &p;
+    const int saved;
+    RunDepth1D(Plan &plan, int times) : p(plan), saved(plan.steps_per_launch) {
+        if (p.ndim == 1 && p.steps_per_launch_req == 0 && p.steps_per_launch == 8 && p.boundary != LORA_BC_PERIODIC)
+            p.steps_per_launch = times >= 64 ? 32 : (times >= 32 ? 16 : 8);
+    }
+    ~RunDepth1D() { p.steps_per_launch = saved; }
+};
+
 int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream) {
     if (!plan || times < 0) return LORA_EINVAL;
     Plan &p = plan->p;
+    RunDepth1D depth(p, times);
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Launch-bound runs (small grids, many steps: the reference's 1D size sweeps in ~2 us per step) are captured
     // once into a hipGraph and replayed; big grids gain nothing and are launched directly.  Capture needs a real
@@ -1101,6 +1117,7 @@ int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *
 int lora_plan_run_profiled(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream,
                            lora_run_profile *profile) {
     if (!plan || times < 0 || !profile) return LORA_EINVAL;
+    RunDepth1D depth(plan->p, times);
     RunMarks marks;
     struct Guard {
         RunMarks &m;

@@ -156,7 +156,11 @@ hipError_t launch_1d_fused(const Plan &p, const double *in, double *out, int beg
     Taps9 w;
     for (int t = 0; t < 9; ++t) w.w[t] = p.w[t];
     const long blocks = ((long) end - begin + kFusedOut - 1) / kFusedOut;
-    if (p.steps_per_launch == 8)
+    if (p.steps_per_launch == 32)
+        hipLaunchKernelGGL((stencil1d_fusedk_kernel<32>), dim3((unsigned) blocks), dim3(256), 0, s, a, w);
+    else if (p.steps_per_launch == 16)
+        hipLaunchKernelGGL((stencil1d_fusedk_kernel<16>), dim3((unsigned) blocks), dim3(256), 0, s, a, w);
+    else if (p.steps_per_launch == 8)
         hipLaunchKernelGGL((stencil1d_fusedk_kernel<8>), dim3((unsigned) blocks), dim3(256), 0, s, a, w);
     else if (p.steps_per_launch == 4)
         hipLaunchKernelGGL((stencil1d_fusedk_kernel<4>), dim3((unsigned) blocks), dim3(256), 0, s, a, w);
