@@ -252,7 +252,7 @@ int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *
 typedef struct lora_run_profile {
     int fused_launches;        /* launches of the K-application kernel                               */
     int apps_per_fused_launch; /* K (1 if the plan does not fuse)                                    */
-    int two_launches;          /* 2D, K = 4: two-application launches that take the tail of the run  */
+    int two_launches;          /* tail launches: 2D, K = 4: two applications each; 1D: K/2, K/4 .. 2 */
     int single_launches;       /* single-sweep launches (the whole run if K = 1)                     */
     float fused_ms;            /* event time of the K-application launches (+ the halo copy)         */
     float two_ms;              /* ... of the two-application tail (+ the halo reset)                 */

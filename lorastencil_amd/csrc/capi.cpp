@@ -862,6 +862,7 @@ int lora_plan_stepk(lora_plan *plan, const void *d_in, void *d_out, void *stream
 struct FusedSchedule {
     int nk = 0, n2 = 0;
     bool scratch = false;  // odd number of fused launches: the last two hops go through the plan's scratch grid
+    int tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 1D: depths of the n2 launches after the nk full-depth ones
 };
 
 static bool ensure_scratch(lora_plan *plan) {
@@ -891,6 +892,39 @@ static FusedSchedule fused_schedule(lora_plan *plan, int times, bool can_fuse, b
     const bool four = p.ndim == 2 && K == 4;
     fs.nk = times / K;
     fs.n2 = four ? (times - K * fs.nk) / 2 : 0;
+    if (p.ndim == 1) {
+        // 1D: what the full-depth launches leave is covered by shallower launches (K / 2, K / 4, ... 2 applications), so
+        // that at most one single sweep remains: 100 sweeps at depth 32 = 32 + 32 + 32 + 4
+        int r = times - K * fs.nk;
+        for (int d = K / 2; d >= 2; d /= 2)
+            if (r >= d) {
+                fs.tail[fs.n2++] = d;
+                r -= d;
+            }
+        const int n1 = fs.nk + fs.n2;
+        if (n1 % 2 == 0) return fs;
+        if (n1 >= 3 && p.use_scratch != 0 && (!allocate || ensure_scratch(plan))) {
+            fs.scratch = true;
+            return fs;
+        }
+        // no scratch grid: an even number of launches -- the last launch becomes two of half its depth, or two single sweeps
+        if (fs.n2 > 0) {
+            const int d = fs.tail[fs.n2 - 1];
+            if (d >= 4) {
+                fs.tail[fs.n2 - 1] = d / 2;
+                fs.tail[fs.n2++] = d / 2;
+            } else {
+                fs.n2 -= 1;
+            }
+        } else if (K >= 4) {
+            fs.nk -= 1;
+            fs.tail[fs.n2++] = K / 2;
+            fs.tail[fs.n2++] = K / 2;
+        } else {
+            fs.nk -= 1;
+        }
+        return fs;
+    }
     const int n = fs.nk + fs.n2;
     if (n % 2 == 0) return fs;
     if (n >= 3 && p.use_scratch != 0 && (!allocate || ensure_scratch(plan))) {
@@ -1012,13 +1046,25 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
                 dst = buf[0];
             }
             if (k == fs.nk) mark(1);
-            const int rc = k < fs.nk ? lora_plan_stepk(plan, src, dst, stream) : lora_plan_step2(plan, src, dst, stream);
+            int rc;
+            if (p.ndim == 1 && k >= fs.nk) {  // a shallower 1D launch: the same kernel at another depth
+                const int depth = p.steps_per_launch;
+                p.steps_per_launch = fs.tail[k - fs.nk];
+                rc = lora_plan_stepk(plan, src, dst, stream);
+                p.steps_per_launch = depth;
+            } else {
+                rc = k < fs.nk ? lora_plan_stepk(plan, src, dst, stream) : lora_plan_step2(plan, src, dst, stream);
+            }
             if (rc != LORA_OK) return rc;
         }
         if (fs.n2 == 0) mark(1);
         if (!dirichlet)
             if (int rc = halo(buf[1], nullptr, lora::HALO_ZERO, "halo reset")) return rc;
         done = K * fs.nk + 2 * fs.n2;
+        if (p.ndim == 1) {
+            done = K * fs.nk;
+            for (int q = 0; q < fs.n2; ++q) done += fs.tail[q];
+        }
         if (marks) marks->fused_launches = fs.nk;
         if (marks) marks->two_launches = fs.n2;
     } else if (!natural3) {
