@@ -182,7 +182,9 @@ int lora_set_default_normalize(int on);
  *                     order changes: identical while values are exact integers, ~1 ulp afterwards)
  *   z_chunk, fused_z_chunk             3D output planes per workgroup (single-sweep / fused kernels; 0 = auto)
  *   stream3           3D fp64 fused launches: 1 = plane-streaming kernel (kernels_3d_planes.hip: LDS-DMA plane ring, three
- *                     applications per launch for the 7-point star, two for the box), 0 = the two-application tile kernel;
+ *                     applications per launch for the 7-point star, two for the box), 0 = the two-application tile kernel,
+ *                     -1 (default) = by grid size: three applications from ~1.2e8 points (star), the plane-streaming
+ *                     kernel with two from ~2.4e7, the tile kernel below;
  *                     stream3_waves (8 / 7 / 6 waves per workgroup, one per CU, or 4, two per CU), stream3_slots (input
  *                     planes in the ring, 0 = as many as fit), stream3_pipe (1 = one barrier per plane, two buffers
  *                     per published level; always on for two applications), stream3_async (1 = no workgroup barriers:

@@ -298,12 +298,27 @@ void plan_refresh(Plan &p) {
         // fp64: THREE applications per launch in the plane-streaming kernel (kernels_3d_planes.hip) -- the grid is read
         // and written once per three sweeps.  An odd count needs no halo copies: launch k starts at global step 3 k and
         // runs on the reference's own buffer state (lora_plan_run)
-        const bool stream3 = p.dtype != LORA_BF16 && !p.generic && p.stream3 != 0;
-        // (the 27-tap box stays at two: its third level makes the launch VALU- and LDS-bound, 465 against 499 GStencils/s
-        // at 768^3 -- asked for explicitly it is available)
-        if (stream3 && p.steps_per_launch == 2 && p.boundary != LORA_BC_PERIODIC &&
-            (p.steps_per_launch_req == 3 || (p.steps_per_launch_req == 0 && p.tapset == TAPS3D_STAR)))
-            p.steps_per_launch = 3;
+        // Which fused kernel: the plane-streaming kernel needs a grid that fills its 60 x 60 tiles and 32-plane chunks a few
+        // times over (tools/small3d.sh, GStencils/s per launch, tile kernel / planes K = 2 / planes K = 3: star 256^3 496 /
+        // 452 / 371, 320^3 458 / 499 / 408, 448^3 562 / 627 / 545, 512^3 497 / 583 / 618, 768^3 530 / 603 / 722; box 256^3
+        // 300 / 307, 320^3 307 / 351, 768^3 446 / 499): three applications from ~1.2e8 points (star), two from ~2.4e7,
+        // the round-1 tile kernel below.  Option stream3: -1 this rule, 0 tile kernel, 1 plane-streaming kernel always;
+        // steps_per_launch = 3 asks for it by itself.  (The 27-tap box stays at two: its third level makes the launch
+        // VALU- and LDS-bound, 465 against 499 GStencils/s at 768^3.)
+        const bool planes_ok = p.dtype != LORA_BF16 && !p.generic && p.stream3 != 0 && p.boundary != LORA_BC_PERIODIC;
+        const double npts = (double) p.dims[0] * p.dims[1] * p.dims[2];
+        bool stream3 = false;
+        if (planes_ok && p.steps_per_launch == 2) {
+            const bool star = p.tapset == TAPS3D_STAR;
+            if (p.steps_per_launch_req == 3) {
+                stream3 = true;
+                p.steps_per_launch = 3;
+            } else if (p.stream3 == 1 || npts >= 2.4e7) {
+                stream3 = true;
+                if (p.steps_per_launch_req == 0 && star && (p.stream3 == 1 || npts >= 1.2e8)) p.steps_per_launch = 3;
+            }
+        }
+        p.stream3_active = stream3 ? 1 : 0;
         p.kernel_name = (p.dtype == LORA_BF16)
                             ? (p.steps_per_launch == 2 ? (p.variant == LORA_VARIANT_MFMA ? kernel_name_3d_bf16_mfma2(p)
                                                                                           : kernel_name_3d_bf16_fused2(p))
@@ -360,7 +375,8 @@ static int step_region(Plan &p, const void *d_in, void *d_out, int begin, int en
 // buffer that carries the caller's halo (what even global levels see outside the interior).
 static int step3_natural(Plan &p, const void *d_in, void *d_out, const void *d_halo, int parity, int begin, int end,
                          void *stream) {
-    if (!(p.ndim == 3 && p.dtype != LORA_BF16 && !p.generic && p.stream3)) return LORA_EUNSUPPORTED;
+    if (!(p.ndim == 3 && p.dtype != LORA_BF16 && !p.generic && p.stream3_active && p.steps_per_launch == 3))
+        return LORA_EUNSUPPORTED;
     if (int rc = check_buffers(d_in, d_out)) return rc;
     if (d_in == d_out || !d_halo || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
     const hipError_t e = launch_3d_stream(p, 3, static_cast<const double *>(d_in), static_cast<double *>(d_out),
@@ -572,7 +588,8 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         if (value < 2 || value > 6) return LORA_EINVAL;
         p.stream_depth = value;
     } else if (!std::strcmp(key, "stream3")) {
-        p.stream3 = value ? 1 : 0;
+        if (value < -1 || value > 1) return LORA_EINVAL;
+        p.stream3 = value;
     } else if (!std::strcmp(key, "stream3_waves")) {
         if (value != 4 && value != 6 && value != 7 && value != 8) return LORA_EINVAL;
         p.stream3_waves = value;
@@ -785,7 +802,7 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
                              ? (p.variant == LORA_VARIANT_MFMA
                                     ? lora::launch_3d_bf16_mfma2(p, d_in, d_out, begin, end, static_cast<hipStream_t>(stream))
                                     : lora::launch_3d_bf16_fused2(p, d_in, d_out, begin, end, static_cast<hipStream_t>(stream)))
-                         : p.stream3
+                         : p.stream3_active
                              ? lora::launch_3d_stream(p, 2, static_cast<const double *>(d_in), static_cast<double *>(d_out),
                                                       static_cast<const double *>(d_in), 0, begin, end,
                                                       static_cast<hipStream_t>(stream))

@@ -428,19 +428,20 @@ def test_1d_fused_k_step_launches_equal_step_by_step(L, O, shape, n):
 # fused 3D fp64 launches: the plane-streaming kernel (three / two applications, its workgroup shapes and the one-barrier
 # pipeline) and the round-1 tile kernel
 FUSED_3D = {
-    "default": {},
+    "default": {},  # grids this small: the tile kernel (the plane-streaming kernel takes over from ~2.4e7 points)
+    "always": {"stream3": 1},
     "stream3": {"steps_per_launch": 3},
     "stream3_w4": {"steps_per_launch": 3, "stream3_waves": 4},
     "stream3_w7": {"steps_per_launch": 3, "stream3_waves": 7},
     "stream3_w6s3": {"steps_per_launch": 3, "stream3_waves": 6, "stream3_slots": 3},
     "stream3_pipe": {"steps_per_launch": 3, "stream3_pipe": 1},
-    "stream2": {"steps_per_launch": 2},
-    "stream2_w4": {"steps_per_launch": 2, "stream3_waves": 4},
-    "stream2_w7pipe": {"steps_per_launch": 2, "stream3_waves": 7, "stream3_pipe": 1},
+    "stream2": {"stream3": 1, "steps_per_launch": 2},
+    "stream2_w4": {"stream3": 1, "steps_per_launch": 2, "stream3_waves": 4},
+    "stream2_w7pipe": {"stream3": 1, "steps_per_launch": 2, "stream3_waves": 7, "stream3_pipe": 1},
     "tile2": {"stream3": 0, "steps_per_launch": 2},
     "async3": {"steps_per_launch": 3, "stream3_async": 1},
     "async3_w4": {"steps_per_launch": 3, "stream3_async": 1, "stream3_waves": 4},
-    "async2": {"steps_per_launch": 2, "stream3_async": 1},
+    "async2": {"stream3": 1, "steps_per_launch": 2, "stream3_async": 1},
 }
 
 
@@ -459,10 +460,12 @@ def test_3d_fused_launches_equal_step_by_step(L, O, shape, dims, cfg):
     for k, v in opts.items():
         plan.set_option(k, v)
     if cfg == "default":
+        assert plan.get_option("steps_per_launch") == 2
+    elif cfg == "always":
         assert plan.get_option("steps_per_launch") == (3 if shape == "star3d1r" else 2)
-    if cfg != "default":
+    else:
         assert plan.get_option("steps_per_launch") == opts["steps_per_launch"]
-    assert plan.kernel_name == ("stencil3d_fused2_kernel" if cfg == "tile2" else "stencil3d_planes_kernel")
+    assert plan.kernel_name == ("stencil3d_fused2_kernel" if cfg in ("tile2", "default") else "stencil3d_planes_kernel")
     for t in (3, 4, 5, 6, 7, 9):
         exp = O.run(shape, a, t)
         for zc in (0, 1, 3, 8):
@@ -555,7 +558,7 @@ def test_3d_stream_kernel_at_scale_equals_single_sweeps(L, shape, dims):
             for extra in ({}, {"stream3_pipe": 1}, {"stream3_async": 1}):
                 if "stream3_async" in extra and wv not in (8, 4):
                     continue
-                got = run(dict({"steps_per_launch": k, "stream3_waves": wv}, **extra), 6)
+                got = run(dict({"stream3": 1, "steps_per_launch": k, "stream3_waves": wv}, **extra), 6)
                 assert torch.equal(got, ref), (shape, k, wv, extra)
 
 
@@ -570,7 +573,7 @@ def test_3d_fused_step2_regions_and_real_weights(L, O):
         if shape == "box3d1r":
             w /= np.abs(w).sum()
         exp = O.run(shape, a, 2, weights=w)  # buffer 0 after two sweeps: interior + the input halo
-        plan = L.Plan(shape, dims).set_weights(w).set_option("steps_per_launch", 2)
+        plan = L.Plan(shape, dims).set_weights(w).set_option("steps_per_launch", 2).set_option("stream3", 1)
         assert plan.kernel_name == "stencil3d_planes_kernel"
         src = torch.from_numpy(a).cuda()
         dst = torch.from_numpy(a).cuda()

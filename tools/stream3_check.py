@@ -20,6 +20,8 @@ def run(shape, dims, w, a, times, opts, boundary):
     plan = L.Plan(shape, dims).set_weights(w)
     if boundary != "reference":
         plan.set_boundary(boundary)
+    if "stream3" not in opts and opts.get("steps_per_launch") != 1:
+        plan.set_option("stream3", 1)  # the plane-streaming kernel whatever the grid size
     for k, v in opts.items():
         plan.set_option(k, v)
     b0 = torch.from_numpy(a).cuda()

@@ -20,6 +20,8 @@ for shape, dims in (("star3d1r", (384, 500, 616)), ("box3d1r", (300, 384, 480)))
 
     def run(opts, times):
         plan = L.Plan(shape, dims).set_weights(w)
+        if "stream3" not in opts and opts.get("steps_per_launch") != 1:
+            plan.set_option("stream3", 1)  # the plane-streaming kernel whatever the grid size
         for k, v in opts.items():
             plan.set_option(k, v)
         b0 = a.clone()
