@@ -85,6 +85,16 @@ __device__ __forceinline__ d2 load_halo_pair(const double *p) {
     return v;
 }
 
+// The same in two halves, for several loads behind one wait: the loads write registers the compiler believes ready,
+// so the wait takes them as in/out operands -- every use comes after it, and the registers stay reserved in between.
+__device__ __forceinline__ void issue_halo_pair(d2 &v, const double *p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(v) : "v"(p) : "memory");
+}
+
+__device__ __forceinline__ void wait_halo_pairs(d2 &a, d2 &b, d2 &c, d2 &d) {
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wait_loads() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -316,18 +326,28 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_planes_kernel(const Args
             // for vmcnt(0) before it uses a loaded register; on the common path that wait drained the whole prefetch
             // stream -- LDS-DMA loads and output stores -- at every publish.)
             if (!(z >= 0 && z < a.h && xy_all[L])) {
+                // the four rows' halo loads are issued together and waited for once: a rim workgroup's plane step would
+                // otherwise carry four serial memory round trips per level, and with one round of long z-chunks the
+                // slowest (rim) workgroups set the launch time
+                d2 hv[kRY];
+                bool need[kRY];
+#pragma unroll
+                for (int r = 0; r < kRY; ++r) {
+                    const bool in = zc_in && row + r >= 0 && row + r < a.m;
+                    const int pz = z + 1, pr = row + r + 2, pc = col + 4;
+                    // cells beyond the padded array feed no valid output
+                    need[r] = !in && lvl_halo[L] && pz >= 0 && pz <= a.h + 1 && pr >= 0 && pr <= a.m + 3 && pc >= 0 &&
+                              pc + 1 <= a.n + 7;
+                    hv[r] = (d2){0.0, 0.0};
+                    if (need[r]) issue_halo_pair(hv[r], a.halo_src + (long) pz * a.plane + (long) pr * a.ld + pc);
+                }
+                if (lvl_halo[L]) wait_halo_pairs(hv[0], hv[1], hv[2], hv[3]);
 #pragma unroll
                 for (int r = 0; r < kRY; ++r) {
                     const bool in = zc_in && row + r >= 0 && row + r < a.m;
                     d2 v;
-                    v.x = in ? x0[L - 1][s][r] : 0.0;
-                    v.y = in ? x1[L - 1][s][r] : 0.0;
-                    if (!in && lvl_halo[L]) {
-                        // cells beyond the padded array feed no valid output
-                        const int pz = z + 1, pr = row + r + 2, pc = col + 4;
-                        if (pz >= 0 && pz <= a.h + 1 && pr >= 0 && pr <= a.m + 3 && pc >= 0 && pc + 1 <= a.n + 7)
-                            v = load_halo_pair(a.halo_src + (long) pz * a.plane + (long) pr * a.ld + pc);
-                    }
+                    v.x = in ? x0[L - 1][s][r] : hv[r].x;
+                    v.y = in ? x1[L - 1][s][r] : hv[r].y;
                     if (!(LORA_ABLATE(a) & 16)) *reinterpret_cast<d2 *>(dst + r * kRowW) = v;
                 }
             } else {
@@ -632,13 +652,13 @@ constexpr size_t stream3_lds_bytes() {
 }
 
 // z-chunk length.  Two applications: the longest chunks (2 K re-read planes each) that still give every workgroup slot
-// of the chip work, in as few whole rounds of workgroups as possible.  Three applications: 32 planes -- measured
-// (tools/zc_sweep.sh, star3d1r 512^3 / 768^3: 603 / 664 GStencils/s against 529 / 549 with one round of 171- / 256-plane
-// chunks): several rounds of short chunks at different depths beat one round of workgroups that walk the same
-// planes in lockstep, although they re-read 6 planes in 38.
+// of the chip work, in as few whole rounds of workgroups as possible.  Three applications: 64 planes -- several rounds
+// of workgroups at different depths (tools/zc_sweep.sh, star3d1r 512^3 / 768^3, GStencils/s: 32 planes 617 / 723, 64:
+// 615 / 729, 86: 572 / 718, 171: 598 / 646, 256: 447 / 651): workgroups on the grid's rim publish through the slower
+// halo path, and in a single round of long chunks they alone set the launch time.
 int stream3_chunk(const Plan &p, int K, int NW, bool pipe, long tiles, int depth) {
     if (p.fused_z_chunk > 0) return p.fused_z_chunk;
-    if (K == 3) return depth < 32 ? depth : 32;
+    if (K == 3) return depth < 64 ? depth : 64;
     const long slots = 256L * (NW == 4 ? 2 : 1);  // workgroups the chip holds at once
     double best = -1.0;
     int best_zc = depth;
