@@ -104,7 +104,10 @@ def run_case(c, rng):
         got, exp = got[:-1], exp[:-1]  # the host operator's copy-back omits the last element
     if not np.isfinite(exp).all():
         return True, "overflow"
-    integer = (not c["real_input"]) and c["taps"] == "default" and np.abs(exp).max() < 2.0 ** 53
+    # "exact" needs every PARTIAL sum below 2^53, not just the results: the structured 2D evaluations (nested profiles,
+    # pyramid forms) add symmetric neighbours before they scale, so their partial sums run a few bits ahead of the
+    # result (seed 12, case box2d3r 1 x 168, 8 sweeps: max 7.6e15 = 2^52.8, one result off by 1 ulp) -- keep 3 bits
+    integer = (not c["real_input"]) and c["taps"] == "default" and np.abs(exp).max() < 2.0 ** 50
     if integer:
         return bool(np.array_equal(got, exp)), "exact"
     den = max(np.abs(exp).max(), 1e-300)
