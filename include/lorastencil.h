@@ -189,8 +189,9 @@ int lora_set_default_normalize(int on);
  *                     planes in the ring, 0 = as many as fit), stream3_pipe (1 = one barrier per plane, two buffers
  *                     per published level; always on for two applications), stream3_async (1 = no workgroup barriers:
  *                     neighbour-wave counters in LDS; bit-identical, measured slower, off)
- *   separable         -1 auto / 0     bf16: exactly separable taps as x/y/z passes (changes the fp32 summation
- *                     order; the oracle restates both orders, see lora_separable_3x3x3)
+ *   separable         -1 auto / 0     exactly separable 3D taps as x/y/z passes: bf16 kernels (changes the fp32 summation
+ *                     order; the oracle restates both orders, see lora_separable_3x3x3) and the fp64 plane-streaming
+ *                     kernel (27 -> 9-10 multiply-adds per point; identical on integer data, ~1e-16 per sweep otherwise)
  *   cols_per_lane, lds_dma, fused_pipeline                              bf16 kernel variants
  *   graph             -1 auto / 0 / 1 : hipGraph replay of lora_plan_run
  *   scratch           -1 auto (= 1) / 0 / 1 : lora_plan_run may allocate one more grid (see there)

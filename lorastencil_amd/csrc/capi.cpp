@@ -307,18 +307,28 @@ void plan_refresh(Plan &p) {
         // VALU- and LDS-bound, 465 against 499 GStencils/s at 768^3.)
         const bool planes_ok = p.dtype != LORA_BF16 && !p.generic && p.stream3 != 0 && p.boundary != LORA_BC_PERIODIC;
         const double npts = (double) p.dims[0] * p.dims[1] * p.dims[2];
+        // Exactly separable fp64 box taps (the reference's: they depend on dx only) are evaluated as x / y / z passes in
+        // the plane-streaming kernel, 9-10 instead of 27 multiply-adds per point (option separable = 0: the 27-tap order);
+        // that makes a third application per launch pay for the box as well
+        double cba64[9];
+        const bool sep_ok = planes_ok && p.tapset == TAPS3D_BOX && p.separable != 0 && separable_27d(p.w, cba64) != 0;
         bool stream3 = false;
         if (planes_ok && p.steps_per_launch == 2) {
-            const bool star = p.tapset == TAPS3D_STAR;
+            const bool three_pays = p.tapset == TAPS3D_STAR || sep_ok;
             if (p.steps_per_launch_req == 3) {
                 stream3 = true;
                 p.steps_per_launch = 3;
             } else if (p.stream3 == 1 || npts >= 2.4e7) {
                 stream3 = true;
-                if (p.steps_per_launch_req == 0 && star && (p.stream3 == 1 || npts >= 1.2e8)) p.steps_per_launch = 3;
+                // (the separable box: 512^3 two applications 593, three 535-589; 768^3 588 / 673 GStencils/s)
+                const double from = p.tapset == TAPS3D_STAR ? 1.2e8 : 3.0e8;
+                if (p.steps_per_launch_req == 0 && three_pays && (p.stream3 == 1 || npts >= from)) p.steps_per_launch = 3;
             }
         }
         p.stream3_active = stream3 ? 1 : 0;
+        p.sep64_valid = (stream3 && sep_ok) ? 1 : 0;
+        if (p.sep64_valid)
+            for (int k = 0; k < 9; ++k) p.sep64[k] = cba64[k];
         p.kernel_name = (p.dtype == LORA_BF16)
                             ? (p.steps_per_launch == 2 ? (p.variant == LORA_VARIANT_MFMA ? kernel_name_3d_bf16_mfma2(p)
                                                                                           : kernel_name_3d_bf16_fused2(p))
@@ -753,12 +763,12 @@ const char *lora_plan_kernel_signature(const lora_plan *plan) {
 {
         const int K = p.steps_per_launch, pipe = (K == 2 || p.stream3_pipe) ? 1 : 0;
         const int nw = lora::stream3_waves(K, pipe, p.stream3_waves);
-        if (p.stream3_async && (p.stream3_waves == 8 || p.stream3_waves == 4))
-            std::snprintf(buf, sizeof buf, "taps=%d,k=%d,waves=%d,async=1,fzc=%d,bc=%d", p.tapset, K, p.stream3_waves,
-                          p.fused_z_chunk, p.boundary);
+        if (p.stream3_async && (nw == 8 || nw == 4))  // the launcher's own condition (kernels_3d_planes.hip)
+            std::snprintf(buf, sizeof buf, "taps=%d,k=%d,waves=%d,async=1,fzc=%d,bc=%d", p.tapset, K, nw, p.fused_z_chunk,
+                          p.boundary);
         else
-            std::snprintf(buf, sizeof buf, "taps=%d,k=%d,waves=%d,slots=%d,pipe=%d,fzc=%d,bc=%d", p.tapset, K, nw,
-                          lora::stream3_slots(K, nw, pipe, p.stream3_slots), pipe, p.fused_z_chunk, p.boundary);
+            std::snprintf(buf, sizeof buf, "taps=%d,k=%d,waves=%d,slots=%d,pipe=%d,fzc=%d,bc=%d", p.sep64_valid ? 2 : p.tapset, K,
+                          nw, lora::stream3_slots(K, nw, pipe, p.stream3_slots), pipe, p.fused_z_chunk, p.boundary);
     }
     else if (p.ndim == 3 && p.dtype == LORA_BF16)
         std::snprintf(buf, sizeof buf, "taps=%d,zc=%d,fzc=%d,cpl=%d,dma=%d,pipe=%d,bc=%d", p.tapset, p.z_chunk,
@@ -1024,18 +1034,41 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
         // run on the reference's own buffer state (buffer 0: the caller's halo, buffer 1: zeros; both the caller's
         // under the Dirichlet option): no halo copies, no parity constraint on the number of launches, no scratch grid.
         // The kernel is told the parity of its first step (which of its inner levels sees which halo).
-        const int nk = times / 3;
-        if (nk > 0) {
+        // What three-application launches leave (1 or 2 sweeps) would be single sweeps at a third of the rate.  When the
+        // launches before them end at an even step in buffer 0, two of them are traded for TWO-application launches of
+        // the same kernel instead: 3 a + 1 = 3 (a - 1) + 2 + 2, 3 a + 2 = 3 (a - 2) + 4 x 2 (50 sweeps = 14 x 3 + 4 x 2).
+        // Those run like every other two-application launch: both buffers carry the caller's halo meanwhile.
+        int nk = times / 3, n2 = 0;
+        const int r = times - 3 * nk;
+        if (r == 1 && nk >= 1 && (nk - 1) % 2 == 0) {
+            nk -= 1;
+            n2 = 2;
+        } else if (r == 2 && nk >= 2 && (nk - 2) % 2 == 0) {
+            nk -= 2;
+            n2 = 4;
+        }
+        if (nk + n2 > 0) {
             if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
             if (!dirichlet)
                 if (int rc = halo(buf[1], nullptr, lora::HALO_ZERO, "halo reset")) return rc;
             for (int k = 0; k < nk; ++k)
                 if (int rc = lora::step3_natural(p, buf[k % 2], buf[(k + 1) % 2], buf[0], k & 1, 0, p.dims[0], stream))
                     return rc;
-            done = 3 * nk;
+            mark(1);
+            if (n2 > 0) {
+                if (!dirichlet)
+                    if (int rc = halo(buf[1], buf[0], lora::HALO_COPY, "halo copy")) return rc;
+                for (int k = 0; k < n2; ++k)
+                    if (int rc = lora_plan_step2(plan, buf[k % 2], buf[(k + 1) % 2], stream)) return rc;
+                if (!dirichlet)
+                    if (int rc = halo(buf[1], nullptr, lora::HALO_ZERO, "halo reset")) return rc;
+            }
+            done = 3 * nk + 2 * n2;
             if (marks) marks->fused_launches = nk;
+            if (marks) marks->two_launches = n2;
+        } else {
+            mark(1);
         }
-        mark(1);
     } else {
         fs = fused_schedule(plan, times, can_fuse);
     }

@@ -17,7 +17,8 @@ int default_params(int shape, double *params);
 int effective_weights(int shape, const double *params, double *weights);
 int factorize_7x7(const double *params, double u[4][7], double v[4][7], double *residual_max);
 int svd_7x7(const double *W, double u[7][7], double v[7][7], double sigma[7]);
-int separable_27(const float *w27, float *cba9);  // exact rank-1 test of fp32 3x3x3 taps; cba = c(x), b(y), a(z)
+int separable_27(const float *w27, float *cba9);
+int separable_27d(const double *w27, double *cba9);  // the same in fp64 (3D fp64 plane-streaming kernel)  // exact rank-1 test of fp32 3x3x3 taps; cba = c(x), b(y), a(z)
 int mfma_factors_27(const float *cba9, float *scale, float *cba9_normalised);  // bf16-exact normalised factors or 0
 
 // ---- tap sets: which of the 49 / 27 taps a kernel instantiation evaluates --------------------
@@ -60,6 +61,8 @@ struct Plan {
     int fused_rows = 8;       // 2D fused: intermediate rows per wave (tile = 4x this - 6 output rows), resolved
     int cols_per_lane = 4;    // 3D bf16: 4 (512-byte row pieces per wave) or 8 (1 KiB)
     int separable = -1;       // 3D bf16: evaluate exactly-separable taps as x/y/z passes: -1 auto (= on), 0 off
+    double sep64[9] = {0};    // fp64 factors c(x), b(y), a(z) of exactly separable 3D taps (plane-streaming kernel)
+    int sep64_valid = 0;      // resolved: the fp64 taps are exactly separable and the option allows that form
     float sep[9] = {0};       // resolved factors c(x), b(y), a(z) when tapset == TAPS3D_SEP
     int mfma_split = 1;       // bf16 MFMA variant: intermediate as hi + lo bf16 halves (1, the contract) or one bf16 rounding (0)
     bool mfma3_valid = false; // bf16: the taps are scale * a (x) b (x) c with bf16-exact normalised factors (MFMA variant)

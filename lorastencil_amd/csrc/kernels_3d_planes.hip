@@ -107,7 +107,7 @@ __device__ __forceinline__ void read_window(const double *row, bool inner, doubl
     const d2 c = *reinterpret_cast<const d2 *>(row + 2);
     win[2] = c.x;
     win[3] = c.y;
-    if (TAPSET == TAPS3D_BOX || inner) {
+    if (TAPSET != TAPS3D_STAR || inner) {
         // Three aligned 16-byte reads (4 LDS cycles each, conflict-free).  Two 8-byte reads of elements 1 and 4 become
         // one ds_read2_b64: 8 cycles and, at a lane stride of 16 bytes, 2-way bank conflicts (30 % of this kernel's LDS
         // cycles in its first version).
@@ -303,8 +303,9 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_planes_kernel(const Args
                 x0[L - 1][0][0] += win[j][1] + win[j][2] + win[j][3] + win[j][4];
                 continue;
             }
-            scatter_row<TAPSET, kRY, PH, true>(x0[L - 1], x1[L - 1], win[j], j, W);
+            if constexpr (TAPSET != TAPS3D_SEP) scatter_row<TAPSET, kRY, PH, true>(x0[L - 1], x1[L - 1], win[j], j, W);
         }
+        if constexpr (TAPSET == TAPS3D_SEP) scatter_plane_sep<kRY, PH, true>(x0[L - 1], x1[L - 1], win, W);
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -566,8 +567,12 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_planes_async_kernel(cons
         } else {
             flag_set(rd_mine + (L - 2) * NW, p + 1);  // the upper neighbour's rows of level L - 1 may be overwritten
         }
+        if constexpr (TAPSET == TAPS3D_SEP) {
+            scatter_plane_sep<kRY, PH, true>(x0[L - 1], x1[L - 1], win, W);
+        } else {
 #pragma unroll
-        for (int j = 0; j < kRY + 2; ++j) scatter_row<TAPSET, kRY, PH, true>(x0[L - 1], x1[L - 1], win[j], j, W);
+            for (int j = 0; j < kRY + 2; ++j) scatter_row<TAPSET, kRY, PH, true>(x0[L - 1], x1[L - 1], win[j], j, W);
+        }
 #pragma unroll
         for (int s = 0; s < 3; ++s)
 #pragma unroll
@@ -716,6 +721,8 @@ hipError_t launch_stream3(const Plan &p, const double *in, double *out, const do
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
     Taps27 w;
     for (int k = 0; k < 27; ++k) w.w[k] = p.w[k];
+    if (TAPSET == TAPS3D_SEP)
+        for (int k = 0; k < 9; ++k) w.w[k] = p.sep64[k];
     constexpr bool ASYNC = NS == 0;  // NS = 0 selects the barrier-free kernel
     constexpr size_t lds = ASYNC ? stream3_async_lds_bytes<K, NW>() : stream3_lds_bytes<K, NW, NS ? NS : 2, PIPE>();
     static_assert(lds <= (NW == 4 ? 80 : 160) * 1024, "LDS budget");
@@ -790,6 +797,8 @@ hipError_t launch_3d_stream(const Plan &p, int K, const double *in, double *out,
     if (K == KK && nw == WW && ns == SS && pipe == PP)                                                                \
         return p.tapset == TAPS3D_STAR                                                                                \
                    ? launch_stream3<TAPS3D_STAR, KK, WW, SS, PP != 0>(p, in, out, halo_src, parity, begin, end, s)    \
+               : p.sep64_valid                                                                                         \
+                   ? launch_stream3<TAPS3D_SEP, KK, WW, SS, PP != 0>(p, in, out, halo_src, parity, begin, end, s)     \
                    : launch_stream3<TAPS3D_BOX, KK, WW, SS, PP != 0>(p, in, out, halo_src, parity, begin, end, s);
     if (p.stream3_async && (nw == 8 || nw == 4)) {  // barrier-free form: 8 waves (one workgroup per CU) or 4 (two)
         const bool star = p.tapset == TAPS3D_STAR;

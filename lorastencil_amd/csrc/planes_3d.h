@@ -57,4 +57,36 @@ __device__ __forceinline__ void scatter_row(double (&x0)[3][RY], double (&x1)[3]
     }
 }
 
+// Exactly separable taps w[dz][dy][dx] = a[dz] b[dy] c[dx] (the reference's box: taps depend on dx only): a plane is
+// filtered along x (3 taps per row of the window), along y (3 rows per cell) and its result added, weighted by a[dz], to
+// the three rotating sets -- 9-10 fused multiply-adds per cell instead of 27.  The summation order differs from the
+// 27-tap form (same value while every partial sum is an exact integer, ~1 ulp per application otherwise).
+// cba = {c[0..2], b[0..2], a[0..2]} in W.w[0..8].
+template <int RY, int PH, bool FRESH>
+__device__ __forceinline__ void scatter_plane_sep(double (&x0)[3][RY], double (&x1)[3][RY], const double (&win)[RY + 2][6],
+                                                  const Taps27 &W) {
+    double t0[RY + 2], t1[RY + 2];
+#pragma unroll
+    for (int j = 0; j < RY + 2; ++j) {
+        t0[j] = fma(W.w[2], win[j][3], fma(W.w[1], win[j][2], W.w[0] * win[j][1]));
+        t1[j] = fma(W.w[2], win[j][4], fma(W.w[1], win[j][3], W.w[0] * win[j][2]));
+    }
+#pragma unroll
+    for (int r = 0; r < RY; ++r) {
+        const double u0 = fma(W.w[5], t0[r + 2], fma(W.w[4], t0[r + 1], W.w[3] * t0[r]));
+        const double u1 = fma(W.w[5], t1[r + 2], fma(W.w[4], t1[r + 1], W.w[3] * t1[r]));
+#pragma unroll
+        for (int dz = 0; dz < 3; ++dz) {
+            const int s = (PH - dz + 3) % 3;
+            if (FRESH && dz == 0) {
+                x0[s][r] = W.w[6] * u0;
+                x1[s][r] = W.w[6] * u1;
+            } else {
+                x0[s][r] = fma(W.w[6 + dz], u0, x0[s][r]);
+                x1[s][r] = fma(W.w[6 + dz], u1, x1[s][r]);
+            }
+        }
+    }
+}
+
 }  // namespace lora

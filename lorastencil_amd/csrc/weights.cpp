@@ -269,6 +269,33 @@ int separable_27(const float *w, float *cba) {
     return 1;
 }
 
+// The same test in fp64 (3D fp64 plane-streaming kernel, TAPS3D_SEP): w[dz][dy][dx] == (a[dz] * b[dy]) * c[dx] with every
+// product rounded to fp64.  Holds for the reference's box taps -- they depend on dx only (3d/gpu_box.cu:151-164) -- and
+// for any scaling of them.
+int separable_27d(const double *w, double *cba) {
+    const double centre = w[13];
+    if (!(centre != 0.0) || !std::isfinite(centre)) return 0;
+    double c[3], b[3], a[3];
+    for (int i = 0; i < 3; ++i) {
+        c[i] = w[9 + 3 + i];
+        b[i] = w[9 + 3 * i + 1] / centre;
+        a[i] = w[9 * i + 3 + 1] / centre;
+    }
+    for (int dz = 0; dz < 3; ++dz)
+        for (int dy = 0; dy < 3; ++dy)
+            for (int dx = 0; dx < 3; ++dx) {
+                const double ab = a[dz] * b[dy];
+                const double abc = ab * c[dx];
+                if (!(abc == w[dz * 9 + dy * 3 + dx])) return 0;
+            }
+    for (int i = 0; i < 3; ++i) {
+        cba[i] = c[i];
+        cba[3 + i] = b[i];
+        cba[6 + i] = a[i];
+    }
+    return 1;
+}
+
 // Factors for the bf16 MFMA variant (kernels_3d_bf16_mfma.hip): separable taps as scale * a' (x) b' (x) c' with the
 // normalised factors (divided by their first entry) EXACT in bf16, so that they can be matrix-instruction operands.
 int mfma_factors_27(const float *cba, float *scale, float *cba_n) {

@@ -462,7 +462,7 @@ def test_3d_fused_launches_equal_step_by_step(L, O, shape, dims, cfg):
     if cfg == "default":
         assert plan.get_option("steps_per_launch") == 2
     elif cfg == "always":
-        assert plan.get_option("steps_per_launch") == (3 if shape == "star3d1r" else 2)
+        assert plan.get_option("steps_per_launch") == 3  # the star, and the box through its separable form
     else:
         assert plan.get_option("steps_per_launch") == opts["steps_per_launch"]
     assert plan.kernel_name == ("stencil3d_fused2_kernel" if cfg in ("tile2", "default") else "stencil3d_planes_kernel")
@@ -558,8 +558,59 @@ def test_3d_stream_kernel_at_scale_equals_single_sweeps(L, shape, dims):
             for extra in ({}, {"stream3_pipe": 1}, {"stream3_async": 1}):
                 if "stream3_async" in extra and wv not in (8, 4):
                     continue
-                got = run(dict({"stream3": 1, "steps_per_launch": k, "stream3_waves": wv}, **extra), 6)
+                # the box's exactly separable taps run as x / y / z passes in this kernel (another summation order than
+                # the single sweeps' 27 taps): bit-identical with that form switched off, to rounding with it
+                got = run(dict({"stream3": 1, "steps_per_launch": k, "stream3_waves": wv, "separable": 0}, **extra), 6)
                 assert torch.equal(got, ref), (shape, k, wv, extra)
+                if shape == "box3d1r" and "stream3_async" not in extra:
+                    got = run(dict({"stream3": 1, "steps_per_launch": k, "stream3_waves": wv}, **extra), 6)
+                    assert float((got - ref).abs().max()) <= 1e-13 * float(ref.abs().max()), (shape, k, wv, extra)
+
+
+@pytest.mark.parametrize("boundary", ["reference", "dirichlet"])
+def test_3d_box_separable_form_against_the_oracle(L, O, boundary):
+    """The reference's box taps depend on dx only (3d/gpu_box.cu:151-164): exactly separable, and the plane-streaming kernel
+    evaluates them as x / y / z passes (9-10 multiply-adds per point instead of 27).  Integer data: bit for bit against
+    the oracle's 27-tap order (every partial sum exact); real data and scaled taps: to rounding; option separable = 0
+    restores the 27-tap order bit for bit."""
+    import torch
+
+    shape, dims = "box3d1r", (21, 70, 124)
+    rng = np.random.default_rng(23)
+    w = O.effective_weights(shape)
+
+    def run(a, w, times, opts):
+        plan = L.Plan(shape, dims).set_weights(w).set_option("stream3", 1)
+        if boundary != "reference":
+            plan.set_boundary(boundary)
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        b0 = torch.from_numpy(a).cuda()
+        b1 = torch.zeros_like(b0)
+        plan.run(b0, b1, times)
+        torch.cuda.synchronize()
+        return (b0, b1)[times % 2].cpu().numpy(), plan
+
+    oracle = (lambda a, w, t: O.run(shape, a, t, weights=w)) if boundary == "reference" else \
+             (lambda a, w, t: O.run_bc(shape, a, t, boundary, weights=w))
+    a_int = O.reference_input(shape, dims)
+    for k in (2, 3):
+        got, plan = run(a_int, w, 4, {"steps_per_launch": k})
+        assert "taps=2" in plan.kernel_signature and plan.get_option("steps_per_launch") == k
+        assert np.array_equal(got, oracle(a_int, w, 4))  # integers below 2^53: exact whatever the order
+        a = rng.standard_normal(O.padded_shape(shape, dims))
+        wn = w / w.sum()
+        for t in (3, 6, 7):
+            exp = oracle(a, wn, t)
+            got, _ = run(a, wn, t, {"steps_per_launch": k})
+            assert rel_err(got, exp) < 1e-13, (k, t)
+            direct, plan = run(a, wn, t, {"steps_per_launch": k, "separable": 0})
+            assert "taps=1" in plan.kernel_signature
+            single, _ = run(a, wn, t, {"steps_per_launch": 1})
+            assert np.array_equal(direct, single), (k, t)
+    # taps that are not exactly separable keep the 27-tap form
+    plan = L.Plan(shape, dims).set_weights(rng.standard_normal(27)).set_option("stream3", 1)
+    assert "taps=1" in plan.kernel_signature
 
 
 def test_3d_fused_step2_regions_and_real_weights(L, O):

@@ -52,6 +52,7 @@ def parity():
                                  {"stream3_pipe": 1, "steps_per_launch": 2, "stream3_waves": 7, "fused_z_chunk": 3},
                                  {"stream3_pipe": 1, "steps_per_launch": 2, "stream3_waves": 6},
                                  {"stream3_pipe": 1, "steps_per_launch": 2, "stream3_waves": 4},
+                                 {"separable": 0}, {"separable": 0, "steps_per_launch": 2},
                                  {"stream3_async": 1}, {"stream3_async": 1, "fused_z_chunk": 4},
                                  {"stream3_async": 1, "stream3_waves": 4},
                                  {"stream3_async": 1, "steps_per_launch": 2},
@@ -64,7 +65,12 @@ def parity():
                             n += 1
                             continue
                         n += 1
-                        if not np.array_equal(ref, got):
+                        same = np.array_equal(ref, got)
+                        if not same and "taps=2" in sig:
+                            # the box's exactly separable taps run as x / y / z passes in the plane-streaming kernel:
+                            # another summation order than the single sweeps' 27 taps
+                            same = float(np.abs(ref - got).max()) <= 1e-13 * float(np.abs(ref).max())
+                        if not same:
                             bad += 1
                             d = np.argwhere(ref != got)
                             print("MISMATCH", shape, dims, boundary, times, opts, sig, len(d), "cells, first", d[:3].tolist(),

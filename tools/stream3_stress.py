@@ -39,7 +39,11 @@ for shape, dims in (("star3d1r", (384, 500, 616)), ("box3d1r", (300, 384, 480)))
                     for rep in range(3):
                         got, sig = run(opts, times)
                         n += 1
-                        if not torch.equal(got, ref):
+                        same = torch.equal(got, ref)
+                        if not same and "taps=2" in sig:
+                            # separable x / y / z evaluation of the box's taps: another summation order
+                            same = float((got - ref).abs().max()) <= 1e-13 * float(ref.abs().max())
+                        if not same:
                             bad += 1
                             print("MISMATCH", shape, times, sig, "rep", rep, int((got != ref).sum()), "cells", flush=True)
         print(shape, times, "done", flush=True)
