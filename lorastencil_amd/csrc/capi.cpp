@@ -303,8 +303,8 @@ void plan_refresh(Plan &p) {
         // 452 / 371, 320^3 458 / 499 / 408, 448^3 562 / 627 / 545, 512^3 497 / 583 / 618, 768^3 530 / 603 / 722; box 256^3
         // 300 / 307, 320^3 307 / 351, 768^3 446 / 499): three applications from ~1.2e8 points (star), two from ~2.4e7,
         // the round-1 tile kernel below.  Option stream3: -1 this rule, 0 tile kernel, 1 plane-streaming kernel always;
-        // steps_per_launch = 3 asks for it by itself.  (The 27-tap box stays at two: its third level makes the launch
-        // VALU- and LDS-bound, 465 against 499 GStencils/s at 768^3.)
+        // steps_per_launch = 3 asks for it by itself.  (In its 27-tap order the box stays at two: the third level makes
+        // the launch VALU- and LDS-bound; its separable form, below, takes three.)
         const bool planes_ok = p.dtype != LORA_BF16 && !p.generic && p.stream3 != 0 && p.boundary != LORA_BC_PERIODIC;
         const double npts = (double) p.dims[0] * p.dims[1] * p.dims[2];
         // Exactly separable fp64 box taps (the reference's: they depend on dx only) are evaluated as x / y / z passes in
