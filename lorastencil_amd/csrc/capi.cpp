@@ -318,7 +318,7 @@ void plan_refresh(Plan &p) {
             if (p.steps_per_launch_req == 3) {
                 stream3 = true;
                 p.steps_per_launch = 3;
-            } else if (p.stream3 == 1 || npts >= 2.4e7) {
+            } else if (p.stream3 == 1 || npts >= (sep_ok ? 2.0e6 : 2.4e7)) {  // (separable box: from ~128^3, tools/rule3d.sh)
                 stream3 = true;
                 // (the separable box: 512^3 two applications 593, three 535-589; 768^3 588 / 673 GStencils/s)
                 const double from = p.tapset == TAPS3D_STAR ? 1.2e8 : 3.0e8;
@@ -601,7 +601,7 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.stream3 = value;
     } else if (!std::strcmp(key, "stream3_waves")) {
-        if (value != 4 && value != 6 && value != 7 && value != 8) return LORA_EINVAL;
+        if (value != 0 && value != 4 && value != 6 && value != 7 && value != 8) return LORA_EINVAL;
         p.stream3_waves = value;
     } else if (!std::strcmp(key, "stream3_async")) {
         p.stream3_async = value ? 1 : 0;
@@ -762,7 +762,7 @@ const char *lora_plan_kernel_signature(const lora_plan *plan) {
     else if (k == "stencil3d_planes_kernel")
 {
         const int K = p.steps_per_launch, pipe = (K == 2 || p.stream3_pipe) ? 1 : 0;
-        const int nw = lora::stream3_waves(K, pipe, p.stream3_waves);
+        const int nw = lora::stream3_waves(p, K, pipe);
         if (p.stream3_async && (nw == 8 || nw == 4))  // the launcher's own condition (kernels_3d_planes.hip)
             std::snprintf(buf, sizeof buf, "taps=%d,k=%d,waves=%d,async=1,fzc=%d,bc=%d", p.tapset, K, nw, p.fused_z_chunk,
                           p.boundary);

@@ -778,7 +778,14 @@ int stream3_slots(int K, int nw, int pipe, int req) {
     return req >= 2 && req <= most ? req : most;
 }
 
-int stream3_waves(int K, int pipe, int req) {
+int stream3_waves(const Plan &p, int K, int pipe) {
+    int req = p.stream3_waves;
+    if (req == 0) {
+        // automatic: 8 waves (one workgroup per CU); two 4-wave workgroups per CU for the separable box on grids below
+        // ~3e7 points (tools/rule3d.sh, box3d1r 128^3 / 192^3 / 256^3: 169 / 351 / 454 against 155 / 323 / 438 GStencils/s)
+        const double npts = (double) p.dims[0] * p.dims[1] * p.dims[2];
+        req = (p.sep64_valid && npts < 3.0e7) ? 4 : 8;
+    }
     const int nw = (req == 4 || req == 6 || req == 7) ? req : 8;
     return (pipe && K == 3) ? 6 : nw;  // the pipelined three-level form fits with 6 waves only
 }
@@ -791,7 +798,7 @@ hipError_t launch_3d_stream(const Plan &p, int K, const double *in, double *out,
     // and "consume" does not keep a fast wave from publishing the next plane over rows a slow neighbour still reads
     // (the three-level form has its second barrier in between) -- found by the full-size tests, invisible on small grids.
     const int pipe = (K == 2 || p.stream3_pipe) ? 1 : 0;
-    const int nw = stream3_waves(K, pipe, p.stream3_waves);
+    const int nw = stream3_waves(p, K, pipe);
     const int ns = stream3_slots(K, nw, pipe, p.stream3_slots);
 #define LORA_S3(KK, WW, SS, PP)                                                                                       \
     if (K == KK && nw == WW && ns == SS && pipe == PP)                                                                \
