@@ -5,8 +5,7 @@
 // (profiles/r02_star3d1r_pmc.json), so the only way up is fewer bytes per application.  This kernel
 //   * fuses THREE applications per launch: the grid is read once and written once per three sweeps;
 //   * uses 512-thread workgroups (62 x 60 / 60 x 60 output tiles from a 66 x 68 input window: 1.21 / 1.25 x instead of
-//     1.28 x) and z-chunks as long as the grid allows while every CU still gets a workgroup (2 K re-read planes per
-//     chunk: 171-plane chunks at 512^3);
+//     1.28 x) and z-chunks of 64 planes for K = 3 (2 K re-read planes per chunk), whole rounds of long chunks for K = 2;
 //   * streams input planes global -> LDS with global_load_lds (no staging registers) into a ring of NS plane slots, the
 //     next plane(s) in flight while the current one is consumed; waits are counted in LOADS only (a younger store may
 //     complete before an older LDS-DMA load: kernels_2d_stream.hip);
@@ -17,7 +16,7 @@
 // Levels.  Level 0 is the input, level l the result of l applications; level l lives in LDS tile T_l (row stride 68
 // doubles), its cells produced by the same lane -> cell map at every level: strip sid = 2 wave + lane / 32 owns rows
 // 4 sid .. 4 sid + 3, lane column pair cl = lane % 32.  A lane reads a window of 6 rows x 4 columns around its cells
-// from T_(l-1) (ds_read_b128 for its own pair, two ds_read_b64 for the neighbours), scatters it into three rotating
+// from T_(l-1) (three aligned ds_read_b128 per row, conflict-free), scatters it into three rotating
 // accumulator sets (planes_3d.h) and publishes the completed plane.  Tile coordinates:
 //   T_0 (i, c)  <->  interior row I - K + i, column J - 4 + c      (padded column J + c: every 16-byte piece aligned)
 //   T_l cell of (sid, r, cl)  <->  interior row I - K + l + 4 sid + r, columns J - 4 + base_l + 2 cl, + 1
@@ -33,7 +32,9 @@
 // keeps the caller's halo.  The input's own halo is whatever `in` holds: with K = 3 the driver (capi.cpp) runs the
 // launches on the reference's natural buffer state (buffer 0: caller's halo, buffer 1: zeros), so launch k reads the
 // halo the reference's step 3 k + 1 would read, and no halo copies or scratch grid are needed.  Taps are applied in the
-// single-sweep kernel's order at every level: the result is bit-identical to K single sweeps.
+// single-sweep kernel's order at every level: the result is bit-identical to K single sweeps -- except for exactly
+// separable box taps (TAPS3D_SEP: the reference's own), which run as x / y / z passes (planes_3d.h, 9-10 instead of 27
+// multiply-adds per point): identical while every partial sum is an exact integer, ~1e-16 relative per sweep otherwise.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
