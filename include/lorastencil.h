@@ -185,8 +185,7 @@ int lora_set_default_normalize(int on);
  *                     applications per launch for the 7-point star, two for the box), 0 = the two-application tile kernel,
  *                     -1 (default) = by grid size: three applications from ~1.2e8 points (star), the plane-streaming
  *                     kernel with two from ~2.4e7, the tile kernel below;
- *                     stream3_waves (0 automatic; 8 / 7 / 6 waves per workgroup, one per CU, or 4, two per CU), stream3_slots (input
- *                     planes in the ring, 0 = as many as fit), stream3_pipe (1 = one barrier per plane, two buffers
+ *                     stream3_waves (0 automatic; 8 waves per workgroup, one per CU, or 4, two per CU), stream3_pipe (1 = one barrier per plane, two buffers
  *                     per published level; always on for two applications), stream3_async (1 = no workgroup barriers:
  *                     neighbour-wave counters in LDS; bit-identical, measured slower, off)
  *   separable         -1 auto / 0     exactly separable 3D taps as x/y/z passes: bf16 kernels (changes the fp32 summation

@@ -601,14 +601,14 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.stream3 = value;
     } else if (!std::strcmp(key, "stream3_waves")) {
-        if (value != 0 && value != 4 && value != 6 && value != 7 && value != 8) return LORA_EINVAL;
+        if (value != 0 && value != 4 && value != 8) return LORA_EINVAL;
         p.stream3_waves = value;
     } else if (!std::strcmp(key, "stream3_async")) {
         p.stream3_async = value ? 1 : 0;
     } else if (!std::strcmp(key, "stream3_pipe")) {
         p.stream3_pipe = value ? 1 : 0;
     } else if (!std::strcmp(key, "stream3_slots")) {
-        if (value < 0 || value > 4) return LORA_EINVAL;
+        if (value != 0 && value != 2) return LORA_EINVAL;  // the ring has two slots (deeper ones measured, no gain)
         p.stream3_slots = value;
     } else if (!std::strcmp(key, "stream_share")) {
         p.stream_share = value ? 1 : 0;

@@ -80,7 +80,7 @@ struct Plan {
     int fused_pipeline = 0;   // 3D bf16 fused: 1 = level 2 one plane behind level 1, one barrier per plane (no gain measured)
     int stream3 = -1;         // 3D fp64 fused: plane-streaming kernel (kernels_3d_planes.hip: 2 or 3 applications per launch) always (1), never (0: the tile kernel, 2 applications), or by grid size (-1)
     int stream3_active = 0;   // resolved: fused launches go through the plane-streaming kernel
-    int stream3_waves = 0;    // 3D plane-streaming kernel: waves per workgroup: 0 = automatic, 8 / 7 / 6 (one workgroup per CU) or 4 (two); output tiles of 8 x waves - 2 (K - 1) rows x 60 columns
+    int stream3_waves = 0;    // 3D plane-streaming kernel: waves per workgroup: 0 = automatic, 8 (one workgroup per CU) or 4 (two); output tiles of 8 x waves - 2 (K - 1) rows x 60 columns
     int stream3_pipe = 0;     // 3D plane-streaming kernel: 1 = every level consumes what was published one step earlier (one barrier per step, two buffers per level)
     int stream3_async = 0;    // 3D plane-streaming kernel: 1 = no workgroup barriers (neighbour-wave counters in LDS, private input rings)
     int stream3_slots = 0;    // 3D plane-streaming kernel: input plane slots of the LDS ring (0 = as many as fit)

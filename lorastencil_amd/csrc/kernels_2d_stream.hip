@@ -36,6 +36,18 @@
 
 namespace lora {
 
+// (a named type: the launcher below is compiled in four parts that hand it to each other, see LORA_STREAM_PART)
+struct ArgsStream {
+    const double *in;
+    double *out;
+    int ld, m, n;
+    int row_begin, row_end;
+    int strips;     // column strips
+    int chunks;     // row chunks of the launch
+    int rows;       // output rows per chunk: 7 groups - 7 K + 1
+    int groups;     // groups of 7 steps per chunk
+};
+
 namespace {
 
 constexpr int kSInW = 128;   // input columns per strip: one 16-byte piece per lane
@@ -51,17 +63,6 @@ __host__ __device__ constexpr int stream_out_w(int K) { return kSInW - 6 * K; }
 // unrolled loop.  K = 4: ten (run-time slot index): the level-2 rows need the input row of 7 steps ago, see below.
 __host__ __device__ constexpr int stream_slots(int K) { return K == 2 ? 7 : 10; }
 __host__ __device__ constexpr int stream_wave_lds(int K) { return stream_slots(K) * kSInW + (K - 1) * kBRow; }
-
-struct ArgsStream {
-    const double *in;
-    double *out;
-    int ld, m, n;
-    int row_begin, row_end;
-    int strips;     // column strips
-    int chunks;     // row chunks of the launch
-    int rows;       // output rows per chunk: 7 groups - 7 K + 1
-    int groups;     // groups of 7 steps per chunk
-};
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -386,6 +387,31 @@ hipError_t launch_stream_e(const Plan &p, const ArgsStream &a, bool dirichlet, h
 
 }  // namespace
 
+hipError_t stream_part0(int eval, int K, const Plan &p, const ArgsStream &a, bool dirichlet, hipStream_t s);
+hipError_t stream_part1(int eval, int K, const Plan &p, const ArgsStream &a, bool dirichlet, hipStream_t s);
+hipError_t stream_part2(int eval, int K, const Plan &p, const ArgsStream &a, bool dirichlet, hipStream_t s);
+hipError_t stream_part3(int eval, int K, const Plan &p, const ArgsStream &a, bool dirichlet, hipStream_t s);
+
+#ifndef LORA_STREAM_PART
+#define LORA_STREAM_PART 0
+#endif
+#define LORA_STREAM_PAIR(NAME, E0, E1)                                                                              \
+    hipError_t NAME(int eval, int K, const Plan &p, const ArgsStream &a, bool dirichlet, hipStream_t s) {          \
+        if (eval == E0) return K == 2 ? launch_stream_e<E0, 2>(p, a, dirichlet, s) : launch_stream_e<E0, 4>(p, a, dirichlet, s); \
+        return K == 2 ? launch_stream_e<E1, 2>(p, a, dirichlet, s) : launch_stream_e<E1, 4>(p, a, dirichlet, s);  \
+    }
+#if LORA_STREAM_PART == 0
+LORA_STREAM_PAIR(stream_part0, EVAL_NEST, TAPS2D_BOX)
+#elif LORA_STREAM_PART == 1
+LORA_STREAM_PAIR(stream_part1, EVAL_LR_DIAMOND, EVAL_LR_PYRAMID)
+#elif LORA_STREAM_PART == 2
+LORA_STREAM_PAIR(stream_part2, EVAL_LR_PYRAMID_SYM, EVAL_LR_PYRAMID_SYM_GAP)
+#else
+LORA_STREAM_PAIR(stream_part3, TAPS2D_DIAMOND, TAPS2D_STAR)
+#endif
+#undef LORA_STREAM_PAIR
+
+#if LORA_STREAM_PART == 0
 // Rows per chunk.  A chunk costs 7 K - 1 extra steps (recomputed rows), so chunks should be long; but the launch should
 // also fill every CU evenly: with j workgroups on most CUs and j + 1 on a few, the few set the pace (measured,
 // star2d1r 16384^2, K = 4: 435 rows = 5.9 workgroups per CU 939 GStencils/s, 582 rows = 4.5 per CU 884; box2d3r 8192^2:
@@ -436,33 +462,34 @@ hipError_t launch_2d_stream(const Plan &p, int K, const double *in, double *out,
     a.rows = stream_rows_per_chunk(p, K, end - begin, a.strips);
     a.groups = (a.rows + 7 * K - 1) / 7;
     a.chunks = (end - begin + a.rows - 1) / a.rows;
-#define LORA_STREAM_K(EV)                                                         \
-    return K == 2 ? launch_stream_e<EV, 2>(p, a, dirichlet, s) : launch_stream_e<EV, 4>(p, a, dirichlet, s);
+    // the instantiations are spread over four translation units (this file compiled with LORA_STREAM_PART = 0 .. 3:
+    // ~200 unrolled kernels took 4.5 minutes in one): each part serves two of the eight tap evaluations
     switch (p.fused_eval) {
         case EVAL_NEST:
-            LORA_STREAM_K(EVAL_NEST)
+            return stream_part0(EVAL_NEST, K, p, a, dirichlet, s);
         case EVAL_LR_DIAMOND:
-            LORA_STREAM_K(EVAL_LR_DIAMOND)
+            return stream_part1(EVAL_LR_DIAMOND, K, p, a, dirichlet, s);
         case EVAL_LR_PYRAMID:
-            LORA_STREAM_K(EVAL_LR_PYRAMID)
+            return stream_part1(EVAL_LR_PYRAMID, K, p, a, dirichlet, s);
         case EVAL_LR_PYRAMID_SYM:
-            LORA_STREAM_K(EVAL_LR_PYRAMID_SYM)
+            return stream_part2(EVAL_LR_PYRAMID_SYM, K, p, a, dirichlet, s);
         case EVAL_LR_PYRAMID_SYM_GAP:
-            LORA_STREAM_K(EVAL_LR_PYRAMID_SYM_GAP)
+            return stream_part2(EVAL_LR_PYRAMID_SYM_GAP, K, p, a, dirichlet, s);
         default:
             break;
     }
     switch (p.tapset) {
         case TAPS2D_DIAMOND:
-            LORA_STREAM_K(TAPS2D_DIAMOND)
+            return stream_part3(TAPS2D_DIAMOND, K, p, a, dirichlet, s);
         case TAPS2D_STAR:
-            LORA_STREAM_K(TAPS2D_STAR)
+            return stream_part3(TAPS2D_STAR, K, p, a, dirichlet, s);
         default:
-            LORA_STREAM_K(TAPS2D_BOX)
+            return stream_part0(TAPS2D_BOX, K, p, a, dirichlet, s);
     }
-#undef LORA_STREAM_K
 }
 
 const char *kernel_name_2d_stream(const Plan &) { return "stencil2d_stream_kernel"; }
+
+#endif  // LORA_STREAM_PART == 0
 
 }  // namespace lora

@@ -766,18 +766,10 @@ hipError_t launch_stream3(const Plan &p, const double *in, double *out, const do
 
 }  // namespace
 
-// workgroup shapes: waves (tile rows 8 NW - 2 (K - 1)), input plane slots and the one-barrier pipeline, bounded by
-// 160 KiB of LDS per CU (80 KiB for two 4-wave workgroups per CU)
-//   K = 3:  8 waves x 2 slots | 7 x 3 | 6 x 4 | 4 x 2 | pipelined: 6 x 2
-//   K = 2 (always pipelined):  8 x 2 | 7 x 3 | 6 x 4 | 4 x 2
-int stream3_slots(int K, int nw, int pipe, int req) {
-    int most;
-    if (pipe || K == 2)
-        most = K == 3 ? 2 : (nw == 8 ? 2 : nw == 7 ? 3 : nw == 6 ? 4 : 2);
-    else
-        most = nw == 8 ? 2 : nw == 7 ? 3 : nw == 6 ? 4 : 2;
-    return req >= 2 && req <= most ? req : most;
-}
+// workgroup shapes, bounded by 160 KiB of LDS per CU (80 KiB for two 4-wave workgroups per CU): 8 waves (one workgroup
+// per CU) or 4 (two), always two input plane slots; the pipelined three-level form fits with 6 waves only.  (Deeper
+// rings -- 7 waves x 3 slots, 6 x 4 -- were built and measured within 3 % of these; they are gone again.)
+int stream3_slots(int, int, int, int) { return 2; }
 
 int stream3_waves(const Plan &p, int K, int pipe) {
     int req = p.stream3_waves;
@@ -787,7 +779,7 @@ int stream3_waves(const Plan &p, int K, int pipe) {
         const double npts = (double) p.dims[0] * p.dims[1] * p.dims[2];
         req = (p.sep64_valid && npts < 3.0e7) ? 4 : 8;
     }
-    const int nw = (req == 4 || req == 6 || req == 7) ? req : 8;
+    const int nw = req == 4 ? 4 : 8;
     return (pipe && K == 3) ? 6 : nw;  // the pipelined three-level form fits with 6 waves only
 }
 
@@ -823,19 +815,9 @@ hipError_t launch_3d_stream(const Plan &p, int K, const double *in, double *out,
                     : launch_stream3<TAPS3D_BOX, 2, 4, 0, false>(p, in, out, halo_src, parity, begin, end, s);
     }
     LORA_S3(3, 8, 2, 0)
-    LORA_S3(3, 7, 3, 0)
-    LORA_S3(3, 7, 2, 0)
-    LORA_S3(3, 6, 4, 0)
-    LORA_S3(3, 6, 3, 0)
-    LORA_S3(3, 6, 2, 0)
     LORA_S3(3, 4, 2, 0)
     LORA_S3(3, 6, 2, 1)
     LORA_S3(2, 8, 2, 1)
-    LORA_S3(2, 7, 3, 1)
-    LORA_S3(2, 7, 2, 1)
-    LORA_S3(2, 6, 4, 1)
-    LORA_S3(2, 6, 3, 1)
-    LORA_S3(2, 6, 2, 1)
     LORA_S3(2, 4, 2, 1)
 #undef LORA_S3
     return hipErrorInvalidValue;

@@ -432,12 +432,10 @@ FUSED_3D = {
     "always": {"stream3": 1},
     "stream3": {"steps_per_launch": 3},
     "stream3_w4": {"steps_per_launch": 3, "stream3_waves": 4},
-    "stream3_w7": {"steps_per_launch": 3, "stream3_waves": 7},
-    "stream3_w6s3": {"steps_per_launch": 3, "stream3_waves": 6, "stream3_slots": 3},
     "stream3_pipe": {"steps_per_launch": 3, "stream3_pipe": 1},
     "stream2": {"stream3": 1, "steps_per_launch": 2},
     "stream2_w4": {"stream3": 1, "steps_per_launch": 2, "stream3_waves": 4},
-    "stream2_w7pipe": {"stream3": 1, "steps_per_launch": 2, "stream3_waves": 7, "stream3_pipe": 1},
+    "stream2_w4pipe": {"stream3": 1, "steps_per_launch": 2, "stream3_waves": 4, "stream3_pipe": 1},
     "tile2": {"stream3": 0, "steps_per_launch": 2},
     "async3": {"steps_per_launch": 3, "stream3_async": 1},
     "async3_w4": {"steps_per_launch": 3, "stream3_async": 1, "stream3_waves": 4},
@@ -554,7 +552,7 @@ def test_3d_stream_kernel_at_scale_equals_single_sweeps(L, shape, dims):
 
     ref = run({"steps_per_launch": 1}, 6)
     for k in (3, 2):
-        for wv in (8, 7, 6, 4):
+        for wv in (8, 4):
             for extra in ({}, {"stream3_pipe": 1}, {"stream3_async": 1}):
                 if "stream3_async" in extra and wv not in (8, 4):
                     continue

@@ -56,7 +56,7 @@ def rand_opts(shape, nd):
         o["stream3"] = pick([-1, 0, 1, 1])
         if o["stream3"] == 0 and o["steps_per_launch"] == 3:
             o["steps_per_launch"] = 2
-        o["stream3_waves"] = pick([8, 8, 7, 6, 4])
+        o["stream3_waves"] = pick([0, 8, 8, 4])
         if rng.random() < 0.3:
             o["stream3_pipe"] = 1
         if rng.random() < 0.2 and o["stream3_waves"] in (8, 4):

@@ -43,14 +43,11 @@ def parity():
                 for times in (3, 4, 6, 7, 11):
                     ref, _ = run(shape, dims, w, a, times, {"steps_per_launch": 1}, boundary)
                     for opts in ({}, {"stream3_waves": 4}, {"steps_per_launch": 2}, {"steps_per_launch": 2, "stream3_waves": 4},
-                                 {"fused_z_chunk": 5}, {"fused_z_chunk": 3, "stream3_waves": 4}, {"stream3_waves": 7},
-                                 {"stream3_waves": 6}, {"stream3_waves": 6, "stream3_slots": 3, "fused_z_chunk": 4},
-                                 {"stream3_waves": 7, "steps_per_launch": 2}, {"stream3_waves": 6, "steps_per_launch": 2},
-                                 {"stream3_waves": 7, "stream3_slots": 2}, {"stream3_slots": 2, "steps_per_launch": 2},
+                                 {"fused_z_chunk": 5}, {"fused_z_chunk": 3, "stream3_waves": 4}, {"fused_z_chunk": 7},
                                  {"stream3_pipe": 1}, {"stream3_pipe": 1, "fused_z_chunk": 4},
                                  {"stream3_pipe": 1, "steps_per_launch": 2},
-                                 {"stream3_pipe": 1, "steps_per_launch": 2, "stream3_waves": 7, "fused_z_chunk": 3},
-                                 {"stream3_pipe": 1, "steps_per_launch": 2, "stream3_waves": 6},
+                                 {"stream3_pipe": 1, "steps_per_launch": 2, "stream3_waves": 4, "fused_z_chunk": 3},
+                                 
                                  {"stream3_pipe": 1, "steps_per_launch": 2, "stream3_waves": 4},
                                  {"separable": 0}, {"separable": 0, "steps_per_launch": 2},
                                  {"stream3_async": 1}, {"stream3_async": 1, "fused_z_chunk": 4},

@@ -33,8 +33,8 @@ for shape, dims in (("star3d1r", (384, 500, 616)), ("box3d1r", (300, 384, 480)))
     for times in (6, 7):
         ref, _ = run({"steps_per_launch": 1}, times)
         for k in (3, 2):
-            for wv in (8, 7, 6, 4):
-                for extra in ({}, {"fused_z_chunk": 32}, {"stream3_pipe": 1}, {"stream3_slots": 2}):
+            for wv in (8, 4):
+                for extra in ({}, {"fused_z_chunk": 32}, {"stream3_pipe": 1}, {"stream3_async": 1}):
                     opts = dict({"steps_per_launch": k, "stream3_waves": wv}, **extra)
                     for rep in range(3):
                         got, sig = run(opts, times)
