@@ -185,6 +185,7 @@ void plan_refresh(Plan &p) {
         // -> 591 (row-streaming, 2) -> 843 GStencils/s (row-streaming, 4: profiles/r02_*).  Four applications per launch exist in the row-streaming kernel, reference boundary (the level-2 halo is the
         // source buffer's own; the Dirichlet option would need source rows 11 steps back)
         if (p.steps_per_launch == 4 && !(p.stream2 && p.boundary == LORA_BC_REFERENCE)) p.steps_per_launch = 2;
+        if (p.steps_per_launch == 6 && !(p.stream2 && p.boundary != LORA_BC_PERIODIC)) p.steps_per_launch = 2;
         p.fused_rows = p.fused_rows_req ? p.fused_rows_req : (p.tapset == TAPS2D_STAR ? 6 : 10);
         // Low-rank evaluation on the vector pipe inside the fused kernel (kernels_2d_fused.hip, apply_row): taken
         // when the factors have the support pattern one of its two forms is specialised for.
@@ -266,7 +267,8 @@ void plan_refresh(Plan &p) {
         p.kernel_name = (p.generic && p.steps_per_launch == 1) ? kernel_name_generic(p)
                         : (p.variant == LORA_VARIANT_MFMA)
                             ? kernel_name_2d_mfma(p)
-                            : (p.steps_per_launch >= 2 ? (p.stream2 ? kernel_name_2d_stream(p) : kernel_name_2d_fused2(p))
+                            : (p.steps_per_launch == 6 ? kernel_name_2d_wg(p)
+                               : p.steps_per_launch >= 2 ? (p.stream2 ? kernel_name_2d_stream(p) : kernel_name_2d_fused2(p))
                                                        : kernel_name_2d_direct(p));
     } else if (p.ndim == 3) {
         bool star = true;
@@ -594,6 +596,12 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "stream_rows")) {
         if (value < 0 || value > (1 << 20)) return LORA_EINVAL;
         p.stream_rows = value;
+    } else if (!std::strcmp(key, "wg_rows")) {
+        if (value < 0 || value > (1 << 20)) return LORA_EINVAL;
+        p.wg_rows = value;
+    } else if (!std::strcmp(key, "wg_edge_pct")) {
+        if (value < -1 || value > 100) return LORA_EINVAL;
+        p.wg_edge_pct = value;
     } else if (!std::strcmp(key, "stream_depth")) {
         if (value < 2 || value > 6) return LORA_EINVAL;
         p.stream_depth = value;
@@ -649,13 +657,14 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         p.fused_rows_req = value;
     } else if (!std::strcmp(key, "steps_per_launch")) {
         const bool three = value == 3 && p.ndim == 3 && p.dtype != LORA_BF16;  // 3D fp64 plane-streaming kernel
-        if (value < 0 || value > 32 || ((value & (value - 1)) && !three)) return LORA_EINVAL;  // 0 (auto), 1, 2, 4, 8, 16, 32
+        const bool six = value == 6 && p.ndim == 2;                             // 2D workgroup-row kernel
+        if (value < 0 || value > 32 || ((value & (value - 1)) && !three && !six)) return LORA_EINVAL;  // 0 (auto), 1, 2, 4, 8, 16, 32
         if (value > 8 && p.ndim != 1) return LORA_EUNSUPPORTED;  // 16 and 32 exist in 1D only
         const bool fusable = (p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && (!p.generic || p.stream2)) ||
                              (p.ndim == 3 && !p.generic) || p.ndim == 1;
         if (value >= 2 && !fusable) return LORA_EUNSUPPORTED;
         if (value > 2 && p.ndim == 3 && !three) return LORA_EUNSUPPORTED;  // 3D: two; three in the fp64 plane-streaming kernel
-        if (value > 4 && p.ndim == 2) return LORA_EUNSUPPORTED;  // 2D: two, or four in the row-streaming kernel
+        if (value > 4 && p.ndim == 2 && !six) return LORA_EUNSUPPORTED;  // 2D: two, four (row-streaming kernel), six (workgroup rows)
         p.steps_per_launch_req = value;
     } else if (!std::strcmp(key, "fused_pipeline")) {
         p.fused_pipeline = value ? 1 : 0;
@@ -853,6 +862,17 @@ int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int b
     if (!plan) return LORA_EINVAL;
     Plan &p = plan->p;
     if (p.steps_per_launch <= 1) return lora_plan_step_region(plan, d_in, d_out, begin, end, stream);
+    if (p.ndim == 2 && p.steps_per_launch == 6) {
+        if (int rc = lora::check_buffers(d_in, d_out)) return rc;
+        if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
+        const hipError_t e = lora::launch_2d_wg(p, 6, static_cast<const double *>(d_in), static_cast<double *>(d_out),
+                                                begin, end, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) {
+            lora::set_last_error("fused 6-step kernel launch", e);
+            return LORA_EHIP;
+        }
+        return LORA_OK;
+    }
     if (p.ndim == 2 && p.steps_per_launch == 4) {
         if (int rc = lora::check_buffers(d_in, d_out)) return rc;
         if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;

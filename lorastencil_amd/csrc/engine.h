@@ -76,6 +76,8 @@ struct Plan {
     int stream_share = 0;     // ... one ring of whole rows per workgroup, a barrier per row (fewer, aligned L2 requests)
     int stream_prefetch = 0;  // ... K = 4: fetch the next level's LDS window while the current level computes (measured: no gain)
     int stream_sync = 1;      // ... s_barrier per 7 rows (1) / per row (2) keeps a workgroup's four strips in step
+    int wg_rows = 0;          // 2D workgroup-row kernel (kernels_2d_wg.hip): output rows per chunk (0 = auto: one round of resident workgroups)
+    int wg_edge_pct = -1;     // ... how much shorter the chunks of the first / last strip are, in per cent of a step's cost (-1 = default)
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
     int fused_pipeline = 0;   // 3D bf16 fused: 1 = level 2 one plane behind level 1, one barrier per plane (no gain measured)
     int stream3 = -1;         // 3D fp64 fused: plane-streaming kernel (kernels_3d_planes.hip: 2 or 3 applications per launch) always (1), never (0: the tile kernel, 2 applications), or by grid size (-1)
@@ -123,6 +125,10 @@ hipError_t launch_2d_stream(const Plan &p, int K, const double *in, double *out,
 const char *kernel_name_2d_stream(const Plan &p);
 int stream_rows_per_chunk(const Plan &p, int K, int rows_total, int strips);  // resolved chunk height of a launch
 int stream_strip_width(int K);
+// K = 6 applications per launch: workgroup-wide rows, levels pipelined over two groups of waves (kernels_2d_wg.hip)
+hipError_t launch_2d_wg(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s);
+const char *kernel_name_2d_wg(const Plan &p);
+int wg_strip_width(int K);
 hipError_t launch_3d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 // two applications per launch, level 1 in LDS (fp64, reference boundary: level-1 halo = 0)
 hipError_t launch_3d_fused2(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
