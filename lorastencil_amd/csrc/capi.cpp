@@ -599,6 +599,9 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "wg_rows")) {
         if (value < 0 || value > (1 << 20)) return LORA_EINVAL;
         p.wg_rows = value;
+    } else if (!std::strcmp(key, "wg_prio")) {
+        if (value < 0 || value > 24) return LORA_EINVAL;
+        p.wg_prio = value;
     } else if (!std::strcmp(key, "wg_edge_pct")) {
         if (value < -1 || value > 100) return LORA_EINVAL;
         p.wg_edge_pct = value;

@@ -77,6 +77,7 @@ struct Plan {
     int stream_prefetch = 0;  // ... K = 4: fetch the next level's LDS window while the current level computes (measured: no gain)
     int stream_sync = 1;      // ... s_barrier per 7 rows (1) / per row (2) keeps a workgroup's four strips in step
     int wg_rows = 0;          // 2D workgroup-row kernel (kernels_2d_wg.hip): output rows per chunk (0 = auto: one round of resident workgroups)
+    int wg_prio = 12;         // ... time-sliced wave priorities that share a CU evenly between its two workgroups: log2 of the slice in 10 ns ticks (0 = off)
     int wg_edge_pct = -1;     // ... how much shorter the chunks of the first / last strip are, in per cent of a step's cost (-1 = default)
     int z_chunk = 16;         // 3D: output planes streamed per workgroup
     int fused_pipeline = 0;   // 3D bf16 fused: 1 = level 2 one plane behind level 1, one barrier per plane (no gain measured)

@@ -29,10 +29,13 @@
 //   * The launch is ONE round: strips x chunks = the workgroups that are resident at once (2 per CU), every chunk as
 //     long as that allows (16384^2: 35 strips x 14 chunks of 1171 rows, 7 K - 1 = 41 recomputed steps each = 3.5 %).
 //   * Halo semantics (as kernels_2d_stream.hip): cells of an intermediate level outside the interior are 0 at
-//     odd levels and the source buffer's own halo value at even levels (every level under the Dirichlet option).  Only
-//     workgroups at the rim of the grid can see such cells: they run a second copy of the loop (EDGE) that forces them,
-//     reading the halo value straight from the input array -- while fused launches run, every buffer carries buffer 0's
-//     halo (capi.cpp) -- so the interior copy has no masks, no selects and no deeper ring for halo sources.
+//     odd levels and the source buffer's own halo value at even levels.  Only workgroups at the rim of the grid can see
+//     such cells: they run a second copy of the step (EDGE) that forces them.  The halo values come straight from the
+//     input array -- while fused launches run, every buffer carries buffer 0's halo (capi.cpp) -- but NOT through a load
+//     the consuming wave waits for: vmcnt completes in order, so that wait would also drain the rows in flight (stage 0) or
+//     the store just issued (last stage), every step (measured: rim workgroups 2.3 x slower).  Instead stage 0 fetches
+//     them one step ahead, global -> LDS like the rows, into a row of halo values per even level (range-checked offsets:
+//     lanes that need nothing make no memory request), where every stage picks them up behind the step's barrier.
 // Per accumulator the taps arrive in the same order as in the other fused 2D kernels: results are bit-identical to them.
 //
 // Replaces the reference's time-step loop 2d/gpu.cu:544-546 (K steps per pass) and kernels 2d/gpu.cu:31-273.
@@ -52,13 +55,17 @@ struct ArgsWG {
     int row_begin, row_end;
     int strips;  // column strips of outw output columns
     int outw;    // output columns per strip: 512 - 6 K
-    int diri;    // Dirichlet option: every intermediate level keeps the source's halo values
     // Row chunks.  The first and the last strip ("rim strips": their lanes see columns outside the interior in every step)
     // run the slower EDGE loop throughout and get shorter chunks, so that every workgroup of the one round takes about
     // the same time: rim strips have chunks_e chunks of rows_e rows, the others chunks_i of rows_i.
     int rim;  // number of rim strips in this launch: 2, or all of them when there are fewer than three
     int rows_i, groups_i, chunks_i;
     int rows_e, groups_e, chunks_e;
+    int prio_split;  // 0, or the number of workgroups dispatched first (one per CU): see the time-sliced priorities in the kernel
+    int prio_shift;  // a priority slice is 2^prio_shift ticks of the 100 MHz counter
+#ifdef LORA_DIAGNOSTICS
+    long long *stamps;  // per workgroup: s_memrealtime at entry / exit, HW_ID, XCC_ID (tools/probes/wg_stamps.hip only)
+#endif
 };
 
 namespace {
@@ -68,7 +75,8 @@ constexpr int kBufW = 520;  // doubles of a level row buffer: the last lanes' wi
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
-__host__ __device__ constexpr int wg_lds_doubles(int K, int D) { return (D + 1) * kRowW + (K - 1) * 2 * kBufW + 8; }
+// ring of input rows | two copies of a row per intermediate level | two copies of a row of halo values per even level
+__host__ __device__ constexpr int wg_lds_doubles(int K, int D) { return (D + 1) * kRowW + (K - 1) * 2 * kBufW + (K / 2 - 1) * 2 * kRowW + 8; }
 
 // Step r of a chunk whose first output row is i0: stage 0 consumes input row i0 - 3 K + r; level l completes its row
 // i0 - 3 K - 4 l + 1 + r (a level lags 3 rows -- its radius -- plus one step of hand-off behind the level below).
@@ -105,6 +113,13 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
         rows = a.rows_i;
         groups = a.groups_i;
     }
+#ifdef LORA_DIAGNOSTICS
+    if (a.stamps && threadIdx.x == 0) {
+        a.stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(63492) | ((long long) __builtin_amdgcn_s_getreg(63508) << 32);
+        a.stamps[4 * blockIdx.x + 3] = ((long long) strip << 32) | (unsigned) chunk;
+    }
+#endif
     const int i0 = a.row_begin + chunk * rows;  // first output row of the chunk (interior coordinates)
     const int j0 = strip * a.outw;              // first output column of the strip
     const int row_hi = min(i0 + rows, a.row_end);
@@ -140,37 +155,48 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
         constexpr int STAGE = decltype(stage_tag)::value;
         constexpr bool FIRST = STAGE == 0;
         constexpr int LB = STAGE * KL;                             // levels LB + 1 .. LB + KL
-        constexpr int NF = (STAGE == S - 1) ? KL - 1 : KL;         // of which the first NF are intermediate (forced) levels
         double pa[KL][7], pb[KL][7];  // rotating partial sums of this wave's KL levels, columns 2 t / 2 t + 1
 #pragma unroll
         for (int j = 0; j < KL; ++j)
 #pragma unroll
             for (int k = 0; k < 7; ++k) pa[j][k] = pb[j][k] = 0.0;
         const double *const winp = lds + 2 * t;  // + constant offsets: every window and row-buffer access of this lane
-        // EDGE: per intermediate level, which of this lane's two columns are interior columns, and the byte offset of its
-        // cell in a padded row (0x80000000 = beyond the descriptor's range: no memory request, reads 0) when it needs the
-        // source's value there -- `hcol` in rows of the interior, `hall` (every lane) in rows outside
-        bool cin0[KL], cin1[KL];
-        unsigned hcol[KL], hall[KL];
+        // EDGE: per intermediate level of this wave, which of the lane's two columns are interior columns
+        // (as all-ones / zero masks)
+        unsigned cmask0[KL], cmask1[KL];
 #pragma unroll
         for (int j = 0; j < KL; ++j) {
-            const int l = LB + j + 1, c0 = j0 - 3 * K + 3 * l + 2 * t;
-            cin0[j] = (unsigned) c0 < (unsigned) a.n;
-            cin1[j] = (unsigned) (c0 + 1) < (unsigned) a.n;
-            const bool keep = (l & 1) == 0 || a.diri != 0;  // even levels: the source buffer's own halo; odd: 0
-            hall[j] = keep ? 8u * (unsigned) min(max(c0 + 4, 0), a.n + 6) : 0x80000000u;
-            hcol[j] = (cin0[j] && cin1[j]) ? 0x80000000u : hall[j];
+            const int c0 = j0 - 3 * K + 3 * (LB + j + 1) + 2 * t;
+            cmask0[j] = (unsigned) c0 < (unsigned) a.n ? ~0u : 0u;
+            cmask1[j] = (unsigned) (c0 + 1) < (unsigned) a.n ? ~0u : 0u;
+            asm volatile("" : "+v"(cmask0[j]), "+v"(cmask1[j]));
         }
+        // Stage 0, EDGE: per even level 2 e + 2 (of ANY stage) the byte offset of this lane's cell in a padded row when the
+        // lane needs the source's value there (0x80000000 = beyond the descriptor's range: no memory request) --
+        // `hcol` in rows of the interior (rim columns only), `hall` in rows outside it (every lane)
+        constexpr int NH = K / 2 - 1;
+        unsigned hcol[NH > 0 ? NH : 1], hall[NH > 0 ? NH : 1];
+        if (FIRST) {
+#pragma unroll
+            for (int e = 0; e < NH; ++e) {
+                const int c0 = j0 - 3 * K + 3 * (2 * e + 2) + 2 * t;
+                hall[e] = 8u * (unsigned) min(max(c0 + 4, 0), a.n + 6);
+                hcol[e] = ((unsigned) c0 < (unsigned) a.n && (unsigned) (c0 + 1) < (unsigned) a.n) ? 0x80000000u : hall[e];
+            }
+        }
+        double *const hb = lds + NS * kRowW + (K - 1) * 2 * kBufW;  // hb + (e * 2 + copy) * kRowW: halo values of level 2 e + 2
 
         auto step = [&](const int r, auto phase_tag, auto edge_tag) {
             constexpr int P = decltype(phase_tag)::value;  // r mod 7: logical row 0 (the one completed now) is acc[P]
             constexpr bool EDGE = decltype(edge_tag)::value;
             const int par = r & 1;
-            // "input row r has landed": the D - 1 younger loads may be outstanding (S > 1: stage 0 has no stores in its
-            // vmcnt; S == 1: as in kernels_2d_stream.hip, the interleaved stores only make the wait stricter)
-            if (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1) : "memory");
-            // one barrier per step: behind it every wave's piece of input row r and every level row of step r - 1 is
-            // visible, and nobody still reads what this step overwrites (ring slot of row r - 1, row copies of step r - 2)
+            // "input row r has landed": the D - 1 younger row loads may be outstanding (S > 1: stage 0 has no stores in its
+            // vmcnt; S == 1: as in kernels_2d_stream.hip, the interleaved stores only make the wait stricter).  EDGE: this
+            // step's halo values were issued in the previous step, BEFORE its row load: one younger load.
+            if (FIRST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(EDGE && NH > 0 ? 1 : D - 1) : "memory");
+            // one barrier per step: behind it every wave's piece of input row r (and of this step's halo values) and every
+            // level row of step r - 1 is visible, and nobody still reads what this step overwrites (ring slot of row r - 1,
+            // row copies of step r - 2, halo values of step r - 1)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -189,17 +215,10 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
                     win[2 * q] = w2.x;
                     win[2 * q + 1] = w2.y;
                 }
-                // EDGE: the source buffer's value of this lane's cell, for the lanes that will need it (while fused launches
-                // run, every buffer carries buffer 0's halo: capi.cpp)
-                u32x4 hraw = {0u, 0u, 0u, 0u};
-                bool row_in = true;
-                if (EDGE && !to_global) {
-                    row_in = (unsigned) row < (unsigned) a.m;
-                    const int pr = min(max(row + 4, 0), a.m + 7);
-                    const __amdgpu_buffer_rsrc_t hsrc = __builtin_amdgcn_make_buffer_rsrc(
-                        const_cast<double *>(a.in) + (size_t) pr * a.ld, 0, (unsigned) a.ld * 8u, 0x00020000);
-                    hraw = __builtin_amdgcn_raw_buffer_load_b128(hsrc, row_in ? hcol[j] : hall[j], 0, 0);
-                }
+                // EDGE: what this lane's cells are forced to when they lie outside the interior
+                d2 h = {0.0, 0.0};
+                if (EDGE && !to_global && (l & 1) == 0)
+                    h = *reinterpret_cast<const d2 *>(winp + NS * kRowW + (K - 1) * 2 * kBufW + ((l / 2 - 1) * 2 + par) * kRowW);
                 // the newest logical row (6) starts from zero: stated here, so that the zero is an inline constant of its
                 // first multiply-add and not a register carried around the loop
                 pa[j][(P + 6) % 7] = 0.0;
@@ -215,17 +234,45 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, store_off, 0, 0);
                 } else {
                     if (EDGE) {
-                        const d2 h = __builtin_bit_cast(d2, hraw);
-                        v.x = (row_in && cin0[j]) ? v.x : h.x;
-                        v.y = (row_in && cin1[j]) ? v.y : h.y;
+                        // v = inside ? v : h as a bitwise blend under integer masks the compiler cannot see through: from a
+                        // select it builds a branch around the row's last multiply-add, and with branches in the step the
+                        // register blow-up is back
+                        const unsigned rmask = (unsigned) row < (unsigned) a.m ? ~0u : 0u;
+                        const unsigned m0 = cmask0[j] & rmask, m1 = cmask1[j] & rmask;
+                        const u32x4 vb = __builtin_bit_cast(u32x4, v), hb4 = __builtin_bit_cast(u32x4, h);
+                        u32x4 o;
+                        o.x = (vb.x & m0) | (hb4.x & ~m0);
+                        o.y = (vb.y & m0) | (hb4.y & ~m0);
+                        o.z = (vb.z & m1) | (hb4.z & ~m1);
+                        o.w = (vb.w & m1) | (hb4.w & ~m1);
+                        v = __builtin_bit_cast(d2, o);
                     }
                     *reinterpret_cast<d2 *>(const_cast<double *>(winp) + NS * kRowW + (l - 1) * 2 * kBufW + cur) = v;
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            // The compiler does not know that the LDS-DMA below overwrites a ring slot; nothing of this step may sink below it
+            // The compiler does not know that the LDS-DMAs below overwrite LDS; nothing of this step may sink below them
             asm volatile("" ::: "memory");
-            if (FIRST) issue(r + D);
+            if (FIRST) {
+                if (EDGE) {
+                    // halo values of step r + 1, every even level: this wave's 128 columns of them
+#pragma unroll
+                    for (int e = 0; e < NH; ++e) {
+                        const int row1 = i0 - 3 * K - 4 * (2 * e + 2) + 1 + (r + 1);
+                        const int pr = min(max(row1 + 4, 0), a.m + 7);
+                        const __amdgpu_buffer_rsrc_t hsrc = __builtin_amdgcn_make_buffer_rsrc(
+                            const_cast<double *>(a.in) + (size_t) pr * a.ld, 0, (unsigned) a.ld * 8u, 0x00020000);
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass does not know this builtin and then drops the kernel's stub without a word)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            hsrc, (__attribute__((address_space(3))) void *) (hb + (e * 2 + (par ^ 1)) * kRowW + wq * 128), 16,
+                            (unsigned) row1 < (unsigned) a.m ? hcol[e] : hall[e], 0, 0, 0);
+#else
+                        (void) hsrc;
+#endif
+                    }
+                }
+                issue(r + D);
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         auto group = [&](const int r0, auto edge_tag) {
@@ -238,22 +285,47 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
             step(r0 + 6, std::integral_constant<int, 6>{}, edge_tag);
         };
 
-        // rows this wave's intermediate levels complete in group g: [lo0 + 7 g, hi0 + 7 g].  Groups [0, g1) and [g2, groups)
-        // have rows outside the interior (first / last chunk only); rim strips run EDGE throughout.  Three plain loops:
-        // a branch inside one loop brings the register blow-up described above back.
-        const int lo0 = i0 - 3 * K - 4 * (LB + NF) + 1, hi0 = i0 - 3 * K - 4 * (LB + 1) + 1 + 6;
-        int g1 = lo0 >= 0 ? 0 : (-lo0 + 6) / 7, g2 = hi0 >= a.m ? 0 : (a.m - hi0 + 6) / 7;
-        if (NF == 0) {
-            g1 = 0;
-            g2 = groups;
-        }
+        // Rows the workgroup's intermediate levels complete in group g: [lo0 + 7 g, hi0 + 7 g].  Groups [0, g1) and
+        // [g2, groups) have rows outside the interior (first / last chunk only); rim strips run EDGE throughout.  The second
+        // EDGE range starts one group early: its first step finds no halo values fetched for it, and needs none there.
+        // The ranges are the same for every wave of the workgroup (stage 0 fetches for all).  Three plain loops: a branch
+        // inside one loop brings the register blow-up described above back.
+        const int lo0 = i0 - 3 * K - 4 * (K - 1) + 1, hi0 = i0 - 3 * K - 4 + 1 + 6;
+        int g1 = lo0 >= 0 ? 0 : (-lo0 + 6) / 7, g2 = hi0 >= a.m ? 0 : (a.m - hi0 + 6) / 7 - 1;
         if (col_edge) g1 = groups;
         g1 = min(g1, groups);
         g2 = min(max(g2, g1), groups);
+        // Two workgroups share a CU, and the SIMD arbiter favours the OLDER wave: left alone, the first-dispatched workgroup
+        // runs at nearly full speed, finishes at 60 % of the launch, and the other one runs the rest of the time without a
+        // partner (measured timeline: tools/probes/wg_stamps.hip -- 730 us and 1180 us on every CU; a workgroup alone
+        // takes 810).  Time-sliced priorities share the CU evenly instead: every group of 7 steps a wave sets its
+        // priority to one bit of the 100 MHz real-time counter (it flips every 2^prio_shift ticks), inverted in the
+        // workgroups dispatched second (block index >= prio_split = number of CUs), so that the two workgroups of a CU
+        // hold complementary priorities and swap them every slice: both progress at the same average rate, finish
+        // together, and neither runs without a partner.
+        const int cls = a.prio_split > 0 ? ((int) blockIdx.x >= a.prio_split ? 1 : 0) : -1;
+        auto slice = [&]() {
+            if (cls >= 0) {
+                const int bit = (int) (__builtin_amdgcn_s_memrealtime() >> a.prio_shift) & 1;
+                if (bit != cls)
+                    __builtin_amdgcn_s_setprio(1);
+                else
+                    __builtin_amdgcn_s_setprio(0);
+            }
+        };
         int g = 0;
-        for (; g < g1; ++g) group(7 * g, std::true_type{});
-        for (; g < g2; ++g) group(7 * g, std::false_type{});
-        for (; g < groups; ++g) group(7 * g, std::true_type{});
+        for (; g < g1; ++g) {
+            slice();
+            group(7 * g, std::true_type{});
+        }
+        for (; g < g2; ++g) {
+            slice();
+            group(7 * g, std::false_type{});
+        }
+        for (; g < groups; ++g) {
+            slice();
+            group(7 * g, std::true_type{});
+        }
     };
     static_assert(S >= 1 && S <= 3, "stages");
     if (stage == 0) run_stage(std::integral_constant<int, 0>{});
@@ -261,6 +333,9 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
         if (stage == 1) run_stage(std::integral_constant<int, 1>{});
     if constexpr (S >= 3)
         if (stage == 2) run_stage(std::integral_constant<int, 2>{});
+#ifdef LORA_DIAGNOSTICS
+    if (a.stamps && threadIdx.x == 0) a.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
     // drain: the last D loads target this workgroup's LDS, which the next workgroup on this CU may own
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -318,6 +393,8 @@ hipError_t launch_wg_t(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
     a.groups_e = (a.rows_e + lag + 6) / 7;
     a.chunks_i = (rows_total + a.rows_i - 1) / a.rows_i;
     a.chunks_e = (rows_total + a.rows_e - 1) / a.rows_e;
+    a.prio_split = (p.wg_prio != 0 && per_cu[dev] == 2) ? cus : 0;
+    a.prio_shift = p.wg_prio > 0 ? p.wg_prio : 12;
     Taps49 w;
     for (int k = 0; k < 49; ++k) w.w[k] = p.w[k];
     LowRankTaps f{};
@@ -348,6 +425,10 @@ hipError_t launch_wg_e(const Plan &p, int K, const ArgsWG &a, int rows_total, hi
 
 int wg_strip_width(int K) { return kRowW - 6 * K; }
 
+#ifdef LORA_DIAGNOSTICS
+long long *g_wg_stamps = nullptr;  // set by the probe: 4 x int64 per workgroup
+#endif
+
 // K applications in one launch over interior rows [begin, end)
 hipError_t launch_2d_wg(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s) {
     if (end <= begin) return hipSuccess;
@@ -362,8 +443,10 @@ hipError_t launch_2d_wg(const Plan &p, int K, const double *in, double *out, int
     a.row_end = end;
     a.outw = wg_strip_width(K);
     a.strips = (a.n + a.outw - 1) / a.outw;
-    a.diri = p.boundary == LORA_BC_DIRICHLET ? 1 : 0;
     a.rim = a.rows_i = a.groups_i = a.chunks_i = a.rows_e = a.groups_e = a.chunks_e = 0;
+#ifdef LORA_DIAGNOSTICS
+    a.stamps = g_wg_stamps;
+#endif
     switch (p.fused_eval) {
         case EVAL_NEST:
             return launch_wg_e<EVAL_NEST>(p, K, a, end - begin, s);
