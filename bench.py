@@ -176,13 +176,17 @@ def self_launch(args) -> int:
 
 
 def planned_launches(ndim, times, spl, fused_ok=True):
-    """(K-application launches, single-sweep launches) of one run: the rule of run_launches() in csrc/capi.cpp -- an
-    even number of K-application launches while at least 2 K steps remain, then single sweeps.  (2D with K = 4 also
-    uses two-application launches for the tail: that schedule is reported by lora_plan_run_profiled itself.)"""
-    if spl < 2 or not fused_ok or times < 2 * spl:
-        return 0, times
-    pairs = (times // spl) & ~1
-    return pairs, times - spl * pairs
+    """(K-application launches, two-application launches, single sweeps) of one SLAB run (world > 1): the rule of
+    SlabDriver.run / lora_slab_run_many -- a fused launch of the driver's K applications whenever the time level is even
+    and K steps remain, then (2D, K >= 4) two-application launches, then single sweeps.  Fused launches all start from
+    level 0 of a run, so every one of them is at an even level.  (The single-GPU schedule, with its scratch-grid routing,
+    is reported by lora_plan_run_profiled itself.)"""
+    if spl < 2 or not fused_ok:
+        return 0, 0, times
+    nk = times // spl
+    rem = times - spl * nk
+    n2 = rem // 2 if (ndim == 2 and spl >= 4) else 0
+    return nk, n2, rem - 2 * n2
 
 
 def main():
@@ -381,9 +385,10 @@ def main():
             kernel, signature = single.kernel_name, single.kernel_signature
     else:
         spl = drv.apps if drv.fused else 1
-        nf, ns = planned_launches(len(dims), K, spl, drv.fused)
-        # slab launches are issued from Python in pieces (boundary strips, interior): count applications, not pieces
-        launches, apps = (nf, spl) if nf else (ns, 1)
+        nf, n2, ns = planned_launches(len(dims), K, spl, drv.fused)
+        # slab launches are issued from Python in pieces (boundary strips, interior): count applications, not pieces;
+        # the K-application launches' share of the timed region is taken as their share of the sweeps
+        launches, apps = (nf, spl) if nf else (max(ns + n2, 1), 1)
         launch_s = ev_ms / 1e3 * (nf * spl / K if nf else 1.0) / max(launches, 1)
     bytes_per_launch = local_points * 2.0 * esize          # compulsory: one read + one write of the grid
     achieved = bytes_per_launch / launch_s / 1e9
@@ -436,7 +441,9 @@ def main():
             },
             "value_reference_convention": round(value * L.ops.gstencil_factor(shape), 3),
             "roofline": {
-                "bound": "hbm" if hbm_frac >= flop_frac else "mfma",
+                # "fp64_valu": the fp64 FMA rate of the vector pipe (78.6 TFLOP/s).  It is also the MFMA f64 rate, and not a
+                # second pipe: v_mfma_f64 and v_fma_f64 share one datapath on gfx950 (profiles/r03_fp64_coissue_probe.txt)
+                "bound": "hbm" if hbm_frac >= flop_frac else "fp64_valu",
                 "kernel": signature,
                 "achieved": round(achieved, 1) if hbm_frac >= flop_frac else round(tflops, 2),
                 "peak": HBM_PEAK_GBS if hbm_frac >= flop_frac else FP64_PEAK_TFLOPS,
@@ -445,7 +452,7 @@ def main():
                 "hbm": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)},
                 "fp64": {"achieved": round(tflops, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(flop_frac, 4), "flops_per_point_algorithmic": FLOPS_PER_POINT.get(shape),
-                         "note": "fp64 matrix peak = vector peak on gfx950; the kernel issues v_fma_f64"},
+                         "note": "fp64 matrix peak = vector peak on gfx950 (one shared datapath); the kernel issues v_fma_f64"},
                 "traffic": traffic,
                 # the same launch duration applied to the MEASURED bytes
                 "traffic_gbs": round(traffic / launch_s / 1e9, 1) if traffic else None,
@@ -456,7 +463,15 @@ def main():
                 "valu_busy": pmc.get("valu_busy"),
                 "mfma_busy": pmc.get("mfma_busy"),
                 "waves_per_simd": pmc.get("waves_per_simd"),
+                # of the vector pipe's issue slots, the share that issued fp64 arithmetic; and the shader clock the chip
+                # held under this kernel (GRBM_GUI_ACTIVE / 8 / duration) -- both from the same profile
+                "valu_issue_frac": pmc.get("fp64_issue_frac"),
+                "clock_ghz": pmc.get("clock_ghz"),
                 "pmc_source": pmc.get("source"),
+                # the chip's clocks ramp up over the first ~50 ms of load and settle after ~100 ms: a shorter
+                # timed region measures the ramp, neither the boost nor the sustained rate
+                "timed_region_ms": round(elapsed * 1e3, 2),
+                "clock_ramp_note": ("timed region < 50 ms: clocks still ramping" if elapsed < 0.05 else None),
                 "launch_us": round(launch_s * 1e6, 2),
                 "launches": launches,
                 "bytes_per_launch": round(bytes_per_launch),
@@ -464,7 +479,7 @@ def main():
                 "frac_one_sweep_equiv": round(one_sweep_equiv / HBM_PEAK_GBS, 4),
                 "copy_gbs": round(copy_gbs, 1) if copy_gbs else None,
                 "copy_bw_frac": round(achieved / copy_gbs, 4) if copy_gbs else None,
-                "two_application_launches": (prof.two_launches if prof else 0),
+                "tail_fused_launches": (prof.two_launches if prof else 0),
                 "single_sweep_launches": (prof.single_launches if prof else None),
             },
         }

@@ -180,12 +180,13 @@ void plan_refresh(Plan &p) {
         if (p.variant == LORA_VARIANT_MFMA || (p.generic && !odd_stream))
             p.steps_per_launch = 1;
         else
-            p.steps_per_launch = p.steps_per_launch_req == 0 ? 4 : p.steps_per_launch_req;
+            p.steps_per_launch = p.steps_per_launch_req == 0 ? 6 : p.steps_per_launch_req;
         // Temporal fusion wins for every tap set: star2d1r 16384^2 352 (one sweep per launch) -> 593 (tile kernel, 2)
         // -> 591 (row-streaming, 2) -> 843 GStencils/s (row-streaming, 4: profiles/r02_*).  Four applications per launch exist in the row-streaming kernel, reference boundary (the level-2 halo is the
         // source buffer's own; the Dirichlet option would need source rows 11 steps back)
         if (p.steps_per_launch == 4 && !(p.stream2 && p.boundary == LORA_BC_REFERENCE)) p.steps_per_launch = 2;
-        if (p.steps_per_launch == 6 && !(p.stream2 && p.boundary != LORA_BC_PERIODIC)) p.steps_per_launch = 2;
+        // six: the workgroup-row kernel (kernels_2d_wg.hip), same conditions; otherwise four, otherwise two
+        if (p.steps_per_launch == 6 && !(p.stream2 && p.boundary == LORA_BC_REFERENCE)) p.steps_per_launch = 2;
         p.fused_rows = p.fused_rows_req ? p.fused_rows_req : (p.tapset == TAPS2D_STAR ? 6 : 10);
         // Low-rank evaluation on the vector pipe inside the fused kernel (kernels_2d_fused.hip, apply_row): taken
         // when the factors have the support pattern one of its two forms is specialised for.
@@ -264,6 +265,9 @@ void plan_refresh(Plan &p) {
                 }
             }
         }
+        // 49 direct taps (no low-rank form) do not fit the scalar registers of the six-application kernel beside its
+        // three levels per wave: such plans keep four applications per launch unless six were asked for
+        if (p.steps_per_launch == 6 && p.steps_per_launch_req == 0 && p.fused_eval == TAPS2D_BOX) p.steps_per_launch = 4;
         p.kernel_name = (p.generic && p.steps_per_launch == 1) ? kernel_name_generic(p)
                         : (p.variant == LORA_VARIANT_MFMA)
                             ? kernel_name_2d_mfma(p)
@@ -763,6 +767,9 @@ const char *lora_plan_kernel_signature(const lora_plan *plan) {
         std::snprintf(buf, sizeof buf, "eval=%d,k=%d,depth=%d,sync=%d%s,rows=%d,bc=%d", p.fused_eval, K, depth,
                       p.stream_sync, p.stream_share ? ",share=1" : ((K == 4 && p.stream_sync == 1 && p.stream_prefetch) ? ",pf=1" : ""), lora::stream_rows_per_chunk(p, K, p.dims[0], (p.dims[1] + w - 1) / w), p.boundary);
     }
+    else if (k == "stencil2d_wg_kernel")
+        std::snprintf(buf, sizeof buf, "eval=%d,k=%d,rows=%d,edge=%d,prio=%d,bc=%d", p.fused_eval, p.steps_per_launch, p.wg_rows,
+                      p.wg_edge_pct, p.wg_prio, p.boundary);
     else if (k == "stencil2d_fused2_kernel")
         std::snprintf(buf, sizeof buf, "eval=%d,rows=%d,persist=%d,panel=%d,bc=%d", p.fused_eval, p.fused_rows,
                       p.persistent, p.panel_width, p.boundary);
@@ -907,12 +914,12 @@ int lora_plan_stepk(lora_plan *plan, const void *d_in, void *d_out, void *stream
 }
 
 // The launches of one run, in order, on `stream` (also what gets captured into a hipGraph).
-// How a run of `times` steps is cut into launches: nk launches of the plan's K applications, n2 two-application launches
-// (2D with K = 4 only), the rest single sweeps.  The fused launches must leave the data in buffer 0.
+// How a run of `times` steps is cut into launches: nk launches of the plan's K applications, n2 shallower fused launches
+// (1D and 2D; their depths in `tail`), the rest single sweeps.  The fused launches must leave the data in buffer 0.
 struct FusedSchedule {
     int nk = 0, n2 = 0;
     bool scratch = false;  // odd number of fused launches: the last two hops go through the plan's scratch grid
-    int tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 1D: depths of the n2 launches after the nk full-depth ones
+    int tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // depths of the n2 launches after the nk full-depth ones
 };
 
 static bool ensure_scratch(lora_plan *plan) {
@@ -939,9 +946,38 @@ static FusedSchedule fused_schedule(lora_plan *plan, int times, bool can_fuse, b
     FusedSchedule fs;
     const int K = p.steps_per_launch;
     if (!can_fuse || K < 2) return fs;
-    const bool four = p.ndim == 2 && K == 4;
     fs.nk = times / K;
-    fs.n2 = four ? (times - K * fs.nk) / 2 : 0;
+    fs.n2 = 0;
+    if (p.ndim == 2) {
+        // 2D: what the full-depth launches leave is covered by one launch of four and / or one of two applications (the
+        // row-streaming kernel), so that at most one single sweep remains: 100 sweeps at depth 6 = 16 x 6 + 4
+        int r = times - K * fs.nk;
+        for (int d = 4; d >= 2; d -= 2)
+            if (d < K && r >= d) {
+                fs.tail[fs.n2++] = d;
+                r -= d;
+            }
+        const int n = fs.nk + fs.n2;
+        if (n % 2 == 0) return fs;
+        if (n >= 3 && p.use_scratch != 0 && (!allocate || ensure_scratch(plan))) {
+            fs.scratch = true;
+            return fs;
+        }
+        // no scratch grid: an even number of launches -- one full-depth launch becomes two shallower ones (6 = 4 + 2,
+        // 4 = 2 + 2), or the last launch becomes single sweeps
+        if (fs.nk >= 1 && K >= 4) {
+            fs.nk -= 1;
+            for (int q = fs.n2 - 1; q >= 0; --q) fs.tail[q + 2] = fs.tail[q];
+            fs.tail[0] = K == 6 ? 4 : 2;
+            fs.tail[1] = 2;
+            fs.n2 += 2;
+        } else if (fs.n2 > 0) {
+            fs.n2 -= 1;
+        } else {
+            fs.nk -= 1;
+        }
+        return fs;
+    }
     if (p.ndim == 1) {
         // 1D: what the full-depth launches leave is covered by shallower launches (K / 2, K / 4, ... 2 applications), so
         // that at most one single sweep remains: 100 sweeps at depth 32 = 32 + 32 + 32 + 4
@@ -981,15 +1017,7 @@ static FusedSchedule fused_schedule(lora_plan *plan, int times, bool can_fuse, b
         fs.scratch = true;
         return fs;
     }
-    // no scratch grid: an even number of launches instead
-    if (four && fs.nk >= 1) {
-        fs.nk -= 1;
-        fs.n2 += 2;
-    } else if (four) {
-        fs.n2 -= 1;
-    } else {
-        fs.nk -= 1;
-    }
+    fs.nk -= 1;  // no scratch grid: an even number of launches instead
     return fs;
 }
 
@@ -1120,7 +1148,7 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
             }
             if (k == fs.nk) mark(1);
             int rc;
-            if (p.ndim == 1 && k >= fs.nk) {  // a shallower 1D launch: the same kernel at another depth
+            if (p.ndim <= 2 && k >= fs.nk) {  // a shallower launch (1D: the same kernel at another depth; 2D: four or two)
                 const int depth = p.steps_per_launch;
                 p.steps_per_launch = fs.tail[k - fs.nk];
                 rc = lora_plan_stepk(plan, src, dst, stream);
@@ -1134,7 +1162,7 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
         if (!dirichlet)
             if (int rc = halo(buf[1], nullptr, lora::HALO_ZERO, "halo reset")) return rc;
         done = K * fs.nk + 2 * fs.n2;
-        if (p.ndim == 1) {
+        if (p.ndim <= 2) {
             done = K * fs.nk;
             for (int q = 0; q < fs.n2; ++q) done += fs.tail[q];
         }

@@ -450,6 +450,14 @@ hipError_t launch_2d_wg(const Plan &p, int K, const double *in, double *out, int
     switch (p.fused_eval) {
         case EVAL_NEST:
             return launch_wg_e<EVAL_NEST>(p, K, a, end - begin, s);
+        case EVAL_LR_DIAMOND:
+            return launch_wg_e<EVAL_LR_DIAMOND>(p, K, a, end - begin, s);
+        case EVAL_LR_PYRAMID:
+            return launch_wg_e<EVAL_LR_PYRAMID>(p, K, a, end - begin, s);
+        case EVAL_LR_PYRAMID_SYM:
+            return launch_wg_e<EVAL_LR_PYRAMID_SYM>(p, K, a, end - begin, s);
+        case EVAL_LR_PYRAMID_SYM_GAP:
+            return launch_wg_e<EVAL_LR_PYRAMID_SYM_GAP>(p, K, a, end - begin, s);
         default:
             break;
     }

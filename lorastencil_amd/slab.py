@@ -146,6 +146,12 @@ class HipStepper:
             self.plan.set_option(k, int(v))
         if boundary == "dirichlet":
             self.plan.set_boundary(boundary)  # fused launches: intermediate halo cells keep the source's values
+        if (len(layout.local_dims) == 2 and self.plan.get_option("steps_per_launch") == 6
+                and "steps_per_launch" not in (options or {})):
+            # the single-GPU driver fuses six sweeps per launch (kernels_2d_wg.hip: one round of long chunks); a slab is a
+            # fraction of the grid's rows, where the 41 recomputed rows of each of its chunks weigh more: slab launches
+            # keep four per launch (row-streaming kernel) unless asked otherwise
+            self.plan.set_option("steps_per_launch", 4)
         if boundary == "periodic":
             self.plan.set_option("steps_per_launch", 1)  # a fused launch would need the wrap of its inner levels
         elif len(layout.local_dims) == 3 and self.plan.get_option("steps_per_launch") > 2:
@@ -231,7 +237,7 @@ class SlabDriver:
         # applications of a fused launch (lora_plan_stepk): 8 in 1D, 4 (row-streaming kernel) or 2 in 2D, 2 in 3D -- the
         # first candidate the stepper agrees with decides the ghost depth
         default_apps = 8 if nd == 1 else 2
-        candidates = {1: [8], 2: [4, 2], 3: [2]}[nd]
+        candidates = {1: [8], 2: [6, 4, 2], 3: [2]}[nd]
         for apps in (candidates + [1] if fused else [1]):
             need = radius * apps
             split = self.world_size > 1 or self._ring
@@ -518,7 +524,7 @@ class SlabDriver:
                 if self.fused and even and times - t >= self.apps:
                     self._launch(self.apps)
                     t += self.apps
-                elif (self.fused and even and self.ndim == 2 and self.apps == 4 and times - t >= 2
+                elif (self.fused and even and self.ndim == 2 and self.apps >= 4 and times - t >= 2
                       and hasattr(self.stepper, "step2_region")):
                     self._launch(2)
                     t += 2

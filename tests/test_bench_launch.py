@@ -34,11 +34,15 @@ def test_planned_launches_follow_the_driver_rule():
     sys.path.insert(0, ROOT)
     import bench
 
-    assert bench.planned_launches(1, 100, 8) == (12, 4)   # 1D: 12 eight-step launches + 4 single sweeps
-    assert bench.planned_launches(2, 100, 2) == (50, 0)
-    assert bench.planned_launches(2, 21, 2) == (10, 1)
-    assert bench.planned_launches(2, 3, 2) == (0, 3)       # fewer than 2 K steps: single sweeps only
-    assert bench.planned_launches(2, 20, 1) == (0, 20)
+    # (K-application launches, two-application launches, single sweeps) of a slab run: SlabDriver.run's rule
+    assert bench.planned_launches(1, 100, 8) == (12, 0, 4)   # 1D: 12 eight-step launches + 4 single sweeps
+    assert bench.planned_launches(2, 100, 2) == (50, 0, 0)
+    assert bench.planned_launches(2, 21, 2) == (10, 0, 1)
+    assert bench.planned_launches(2, 20, 4) == (5, 0, 0)      # an odd number of fused launches is fine in a slab run
+    assert bench.planned_launches(2, 23, 4) == (5, 1, 1)      # 2D, K = 4: a two-application launch for the tail
+    assert bench.planned_launches(2, 23, 6) == (3, 2, 1)
+    assert bench.planned_launches(3, 7, 2) == (3, 0, 1)
+    assert bench.planned_launches(2, 20, 1) == (0, 0, 20)
 
 
 @pytest.mark.gpu
@@ -57,9 +61,10 @@ def test_bench_line_roofline_is_a_fraction():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(lines[-1])
     rf = d["roofline"]
-    assert d["n_gpus"] == 1 and 0 < rf["frac"] <= 1.0 and rf["applications_per_launch"] == 4
+    assert d["n_gpus"] == 1 and 0 < rf["frac"] <= 1.0 and rf["applications_per_launch"] == 6
     assert 0 < rf["hbm"]["frac"] <= 1.0 and 0 < rf["fp64"]["frac"] <= 1.0
-    assert rf["frac"] == max(rf["hbm"]["frac"], rf["fp64"]["frac"]) and rf["bound"] in ("hbm", "mfma")
-    assert abs(rf["frac_one_sweep_equiv"] - 4 * rf["hbm"]["frac"]) < 1e-3 and rf["launches"] == 2
+    assert rf["frac"] == max(rf["hbm"]["frac"], rf["fp64"]["frac"]) and rf["bound"] in ("hbm", "fp64_valu")
+    assert abs(rf["frac_one_sweep_equiv"] - 6 * rf["hbm"]["frac"]) < 1e-3 and rf["launches"] == 1   # 8 sweeps = 6 + 2
+    assert rf["tail_fused_launches"] == 1 and rf["clock_ramp_note"] is not None
     assert rf["traffic"] is None or rf["traffic_key"].endswith(rf["kernel"])  # never a number of another kernel
     assert d["cpu_baseline"]["cores"] >= 1

@@ -175,8 +175,10 @@ def test_shape_tables(L):
 
 
 def test_plan_validation(L):
-    # odd innermost extent: the row-streaming kernel for fused launches, the generic fallback for single sweeps / 3D
-    assert L.Plan("star2d1r", (64, 127)).kernel_name == "stencil2d_stream_kernel"
+    # odd innermost extent: the fused 2D kernels (six applications: workgroup rows; four / two: row streaming) take it,
+    # the generic fallback serves single sweeps / 3D
+    assert L.Plan("star2d1r", (64, 127)).kernel_name == "stencil2d_wg_kernel"
+    assert L.Plan("star2d1r", (64, 127)).set_option("steps_per_launch", 4).kernel_name == "stencil2d_stream_kernel"
     assert L.Plan("star2d1r", (64, 127)).set_option("steps_per_launch", 1).kernel_name == "stencil2d_generic_kernel"
     assert L.Plan("box3d1r", (4, 4, 5)).kernel_name == "stencil3d_generic_kernel"
     with pytest.raises(L.LoraError):
@@ -236,7 +238,18 @@ def test_diagnostics_are_not_in_the_shipped_library(L, monkeypatch):
 
 def test_kernel_signature_names_every_selecting_option(L):
     p = L.Plan("star2d1r", (16384, 16384))
-    assert p.kernel_name == "stencil2d_stream_kernel"  # the default 2D kernel: row-streaming, four applications
+    assert p.kernel_name == "stencil2d_wg_kernel"  # the default 2D kernel: workgroup rows, six applications per launch
+    assert p.get_option("steps_per_launch") == 6
+    assert p.kernel_signature.startswith(p.kernel_name + "[") and "eval=7" in p.kernel_signature and "k=6" in p.kernel_signature
+    s6 = p.kernel_signature
+    p.set_option("wg_edge_pct", 20)
+    assert p.kernel_signature != s6
+    # plain 49-tap tables (no low-rank form) keep four applications per launch; the Dirichlet option two
+    q = L.Plan("star2d1r", (256, 512)).set_weights(np.random.default_rng(3).random(49))
+    assert q.get_option("steps_per_launch") == 4 and q.kernel_name == "stencil2d_stream_kernel"
+    assert L.Plan("star2d1r", (256, 512)).set_boundary("dirichlet").get_option("steps_per_launch") == 2
+    p = L.Plan("star2d1r", (16384, 16384)).set_option("steps_per_launch", 4)
+    assert p.kernel_name == "stencil2d_stream_kernel"  # row-streaming, four applications
     assert p.kernel_signature.startswith(p.kernel_name + "[") and "eval=7" in p.kernel_signature
     assert "k=4" in p.kernel_signature and "depth=" in p.kernel_signature and "rows=" in p.kernel_signature
     s0 = p.kernel_signature

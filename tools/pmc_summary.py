@@ -77,6 +77,10 @@ def main():
                 e["waves_per_simd"] = e["SQ_WAVE_CYCLES"]["mean"] / simd_quads
                 if "SQ_ACTIVE_INST_VALU" in cs:
                     e["valu_busy"] = e["SQ_ACTIVE_INST_VALU"]["mean"] / simd_quads
+                if "SQ_INSTS_VALU_FMA_F64" in cs:
+                    # fp64 arithmetic instructions x 4 cycles each (16 lanes per cycle) of the SIMD cycles available
+                    # (SQ_INSTS_VALU_FMA_F64 counts v_fma / v_mul / v_add _f64)
+                    e["fp64_issue_frac"] = e["SQ_INSTS_VALU_FMA_F64"]["mean"] * 4.0 / (cyc * 1024.0)
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in cs:
                     e["mfma_busy"] = e["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (cyc * 1024.0)
             summary[k] = e
@@ -92,6 +96,8 @@ def main():
                                        "valu_busy": round(best["valu_busy"], 3) if "valu_busy" in best else None,
                                        "mfma_busy": round(best["mfma_busy"], 3) if "mfma_busy" in best else None,
                                        "waves_per_simd": round(best["waves_per_simd"], 2) if "waves_per_simd" in best else None,
+                                       "fp64_issue_frac": round(best["fp64_issue_frac"], 3) if "fp64_issue_frac" in best else None,
+                                       "clock_ghz": round(best["clock_ghz"], 3) if "clock_ghz" in best else None,
                                        "source": f"profiles/{args.tag}_pmc.json"}
                 json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
                 print("traffic", args.traffic_key, t[args.traffic_key])
