@@ -268,10 +268,16 @@ void plan_refresh(Plan &p) {
         // 49 direct taps (no low-rank form) do not fit the scalar registers of the six-application kernel beside its
         // three levels per wave: such plans keep four applications per launch unless six were asked for
         if (p.steps_per_launch == 6 && p.steps_per_launch_req == 0 && p.fused_eval == TAPS2D_BOX) p.steps_per_launch = 4;
+        // which kernel family lora_plan_stepk launches: the workgroup-row kernel for six applications and, in such plans,
+        // for the four- and two-application tails of a run; plans that ask for four or two keep the row-streaming kernel
+        // (option wg = 1: the workgroup-row kernel at every depth)
+        p.wg_active = p.stream2 && p.boundary == LORA_BC_REFERENCE && p.variant == LORA_VARIANT_DIRECT &&
+                      (p.steps_per_launch == 6 || (p.wg == 1 && p.steps_per_launch >= 2)) && p.wg != 0;
+        if (p.steps_per_launch == 6 && !p.wg_active) p.steps_per_launch = 4;
         p.kernel_name = (p.generic && p.steps_per_launch == 1) ? kernel_name_generic(p)
                         : (p.variant == LORA_VARIANT_MFMA)
                             ? kernel_name_2d_mfma(p)
-                            : (p.steps_per_launch == 6 ? kernel_name_2d_wg(p)
+                            : (p.wg_active ? kernel_name_2d_wg(p)
                                : p.steps_per_launch >= 2 ? (p.stream2 ? kernel_name_2d_stream(p) : kernel_name_2d_fused2(p))
                                                        : kernel_name_2d_direct(p));
     } else if (p.ndim == 3) {
@@ -600,6 +606,9 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "stream_rows")) {
         if (value < 0 || value > (1 << 20)) return LORA_EINVAL;
         p.stream_rows = value;
+    } else if (!std::strcmp(key, "wg")) {
+        if (value < -1 || value > 1) return LORA_EINVAL;
+        p.wg = value;
     } else if (!std::strcmp(key, "wg_rows")) {
         if (value < 0 || value > (1 << 20)) return LORA_EINVAL;
         p.wg_rows = value;
@@ -872,13 +881,13 @@ int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int b
     if (!plan) return LORA_EINVAL;
     Plan &p = plan->p;
     if (p.steps_per_launch <= 1) return lora_plan_step_region(plan, d_in, d_out, begin, end, stream);
-    if (p.ndim == 2 && p.steps_per_launch == 6) {
+    if (p.ndim == 2 && (p.steps_per_launch == 6 || (p.wg_active && (p.steps_per_launch == 4 || p.steps_per_launch == 2)))) {
         if (int rc = lora::check_buffers(d_in, d_out)) return rc;
         if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
-        const hipError_t e = lora::launch_2d_wg(p, 6, static_cast<const double *>(d_in), static_cast<double *>(d_out),
-                                                begin, end, static_cast<hipStream_t>(stream));
+        const hipError_t e = lora::launch_2d_wg(p, p.steps_per_launch, static_cast<const double *>(d_in),
+                                                static_cast<double *>(d_out), begin, end, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) {
-            lora::set_last_error("fused 6-step kernel launch", e);
+            lora::set_last_error("fused workgroup-row kernel launch", e);
             return LORA_EHIP;
         }
         return LORA_OK;
@@ -952,6 +961,14 @@ static FusedSchedule fused_schedule(lora_plan *plan, int times, bool can_fuse, b
         // 2D: what the full-depth launches leave is covered by one launch of four and / or one of two applications (the
         // row-streaming kernel), so that at most one single sweep remains: 100 sweeps at depth 6 = 16 x 6 + 4
         int r = times - K * fs.nk;
+        if (K == 6 && r >= 2 && r < 4 && fs.nk >= 1) {
+            // 6 + 2 as 4 + 4: a two-application launch moves the whole grid for two sweeps (star2d1r 16384^2, us per
+            // launch of the workgroup-row kernel at 6 / 4 / 2 applications: 1194 / 944 / 885)
+            fs.nk -= 1;
+            fs.tail[fs.n2++] = 4;
+            fs.tail[fs.n2++] = 4;
+            r -= 2;
+        }
         for (int d = 4; d >= 2; d -= 2)
             if (d < K && r >= d) {
                 fs.tail[fs.n2++] = d;

@@ -76,6 +76,8 @@ struct Plan {
     int stream_share = 0;     // ... one ring of whole rows per workgroup, a barrier per row (fewer, aligned L2 requests)
     int stream_prefetch = 0;  // ... K = 4: fetch the next level's LDS window while the current level computes (measured: no gain)
     int stream_sync = 1;      // ... s_barrier per 7 rows (1) / per row (2) keeps a workgroup's four strips in step
+    int wg = -1;              // 2D fused launches through the workgroup-row kernel (kernels_2d_wg.hip): -1 = when the plan fuses six applications per launch (then also its four / two tails), 0 never, 1 always
+    int wg_active = 0;        // resolved
     int wg_rows = 0;          // 2D workgroup-row kernel (kernels_2d_wg.hip): output rows per chunk (0 = auto: one round of resident workgroups)
     int wg_prio = 12;         // ... time-sliced wave priorities that share a CU evenly between its two workgroups: log2 of the slice in 10 ns ticks (0 = off)
     int wg_edge_pct = -1;     // ... how much shorter the chunks of the first / last strip are, in per cent of a step's cost (-1 = default)
@@ -126,7 +128,7 @@ hipError_t launch_2d_stream(const Plan &p, int K, const double *in, double *out,
 const char *kernel_name_2d_stream(const Plan &p);
 int stream_rows_per_chunk(const Plan &p, int K, int rows_total, int strips);  // resolved chunk height of a launch
 int stream_strip_width(int K);
-// K = 6 applications per launch: workgroup-wide rows, levels pipelined over two groups of waves (kernels_2d_wg.hip)
+// K = 6, 4 or 2 applications per launch: workgroup-wide rows, levels pipelined over two groups of waves (kernels_2d_wg.hip)
 hipError_t launch_2d_wg(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s);
 const char *kernel_name_2d_wg(const Plan &p);
 int wg_strip_width(int K);

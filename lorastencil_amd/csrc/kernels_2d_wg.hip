@@ -368,8 +368,10 @@ hipError_t launch_wg_t(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
     };
     a.rim = a.strips >= 3 ? 2 : a.strips;
     const int ni = a.strips - a.rim;
-    // a rim-strip step costs about edge_pct per cent more than an interior one (the EDGE loop's selects and cell loads)
-    const int pct = p.wg_edge_pct >= 0 ? p.wg_edge_pct : 12;
+    // A rim-strip workgroup runs the EDGE steps throughout (selects, halo-value fetches, one row less in flight) and takes
+    // about half as long again per step: its chunks are that much shorter (16384^2, us per launch at 12 / 25 / 35 / 45 /
+    // 55 / 70 per cent: 1393 / 1391 / 1237 / 1189 / 1172 / 1164; gpurun_out/wg_sweep.log)
+    const int pct = p.wg_edge_pct >= 0 ? p.wg_edge_pct : 60;
     auto rim_rows = [&](int rows_i) { return fit(std::max(1L, (long) (rows_i + lag) * 100 / (100 + pct) - lag)); };
     if (p.wg_rows > 0) {
         a.rows_i = fit(p.wg_rows);
@@ -415,13 +417,51 @@ hipError_t launch_wg_t(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
     return hipGetLastError();
 }
 
+// This file is compiled once per launch depth (LORA_WG_K = 6, 4, 2: eight tap evaluations each).  Two stages of K / 2
+// levels, three rows in flight, four waves per SIMD in every case.
+#ifndef LORA_WG_K
+#define LORA_WG_K 6
+#endif
 template <int EVAL>
-hipError_t launch_wg_e(const Plan &p, int K, const ArgsWG &a, int rows_total, hipStream_t s) {
-    if (K == 6) return launch_wg_t<EVAL, 3, 2, 3, 4>(p, a, rows_total, s);
-    return hipErrorInvalidValue;
+hipError_t launch_wg_e(const Plan &p, const ArgsWG &a, int rows_total, hipStream_t s) {
+    return launch_wg_t<EVAL, LORA_WG_K / 2, 2, 3, 4>(p, a, rows_total, s);
 }
 
 }  // namespace
+
+#define LORA_WG_CAT2(a, b) a##b
+#define LORA_WG_CAT(a, b) LORA_WG_CAT2(a, b)
+#define LORA_WG_ENTRY LORA_WG_CAT(launch_2d_wg_k, LORA_WG_K)
+
+// LORA_WG_K applications in one launch over interior rows [begin, end)
+hipError_t LORA_WG_ENTRY(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
+    switch (p.fused_eval) {
+        case EVAL_NEST:
+            return launch_wg_e<EVAL_NEST>(p, a, rows_total, s);
+        case EVAL_LR_DIAMOND:
+            return launch_wg_e<EVAL_LR_DIAMOND>(p, a, rows_total, s);
+        case EVAL_LR_PYRAMID:
+            return launch_wg_e<EVAL_LR_PYRAMID>(p, a, rows_total, s);
+        case EVAL_LR_PYRAMID_SYM:
+            return launch_wg_e<EVAL_LR_PYRAMID_SYM>(p, a, rows_total, s);
+        case EVAL_LR_PYRAMID_SYM_GAP:
+            return launch_wg_e<EVAL_LR_PYRAMID_SYM_GAP>(p, a, rows_total, s);
+        default:
+            break;
+    }
+    switch (p.tapset) {
+        case TAPS2D_DIAMOND:
+            return launch_wg_e<TAPS2D_DIAMOND>(p, a, rows_total, s);
+        case TAPS2D_STAR:
+            return launch_wg_e<TAPS2D_STAR>(p, a, rows_total, s);
+        default:
+            return launch_wg_e<TAPS2D_BOX>(p, a, rows_total, s);
+    }
+}
+
+#if LORA_WG_K == 6
+hipError_t launch_2d_wg_k4(const Plan &p, ArgsWG a, int rows_total, hipStream_t s);
+hipError_t launch_2d_wg_k2(const Plan &p, ArgsWG a, int rows_total, hipStream_t s);
 
 int wg_strip_width(int K) { return kRowW - 6 * K; }
 
@@ -429,10 +469,11 @@ int wg_strip_width(int K) { return kRowW - 6 * K; }
 long long *g_wg_stamps = nullptr;  // set by the probe: 4 x int64 per workgroup
 #endif
 
-// K applications in one launch over interior rows [begin, end)
+// K = 6, 4 or 2 applications in one launch over interior rows [begin, end)
 hipError_t launch_2d_wg(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s) {
     if (end <= begin) return hipSuccess;
-    if (K != 6) return hipErrorInvalidValue;
+    if (K != 6 && K != 4 && K != 2) return hipErrorInvalidValue;
+    if (p.boundary != LORA_BC_REFERENCE) return hipErrorNotSupported;  // (halo values exist for the even levels only)
     ArgsWG a;
     a.in = in;
     a.out = out;
@@ -444,33 +485,19 @@ hipError_t launch_2d_wg(const Plan &p, int K, const double *in, double *out, int
     a.outw = wg_strip_width(K);
     a.strips = (a.n + a.outw - 1) / a.outw;
     a.rim = a.rows_i = a.groups_i = a.chunks_i = a.rows_e = a.groups_e = a.chunks_e = 0;
+    a.prio_split = a.prio_shift = 0;
 #ifdef LORA_DIAGNOSTICS
     a.stamps = g_wg_stamps;
 #endif
-    switch (p.fused_eval) {
-        case EVAL_NEST:
-            return launch_wg_e<EVAL_NEST>(p, K, a, end - begin, s);
-        case EVAL_LR_DIAMOND:
-            return launch_wg_e<EVAL_LR_DIAMOND>(p, K, a, end - begin, s);
-        case EVAL_LR_PYRAMID:
-            return launch_wg_e<EVAL_LR_PYRAMID>(p, K, a, end - begin, s);
-        case EVAL_LR_PYRAMID_SYM:
-            return launch_wg_e<EVAL_LR_PYRAMID_SYM>(p, K, a, end - begin, s);
-        case EVAL_LR_PYRAMID_SYM_GAP:
-            return launch_wg_e<EVAL_LR_PYRAMID_SYM_GAP>(p, K, a, end - begin, s);
-        default:
-            break;
-    }
-    switch (p.tapset) {
-        case TAPS2D_DIAMOND:
-            return launch_wg_e<TAPS2D_DIAMOND>(p, K, a, end - begin, s);
-        case TAPS2D_STAR:
-            return launch_wg_e<TAPS2D_STAR>(p, K, a, end - begin, s);
-        default:
-            return launch_wg_e<TAPS2D_BOX>(p, K, a, end - begin, s);
-    }
+#ifdef LORA_WG_ONLY_K6  // (tools/probes/wg_stamps.hip includes this file alone)
+    return launch_2d_wg_k6(p, a, end - begin, s);
+#else
+    return K == 6 ? launch_2d_wg_k6(p, a, end - begin, s)
+                  : (K == 4 ? launch_2d_wg_k4(p, a, end - begin, s) : launch_2d_wg_k2(p, a, end - begin, s));
+#endif
 }
 
 const char *kernel_name_2d_wg(const Plan &) { return "stencil2d_wg_kernel"; }
+#endif  // LORA_WG_K == 6
 
 }  // namespace lora

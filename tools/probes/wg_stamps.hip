@@ -3,6 +3,7 @@
 // which CU, who sets the pace -- can be read.  star2d1r taps, 16384^2 by default.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DLORA_DIAGNOSTICS -I../../include -I../../lorastencil_amd/csrc \
 //         -o bin/wg_stamps wg_stamps.hip && ./bin/wg_stamps [m n [wg_rows [edge_pct [prio]]]] > stamps.csv
+#define LORA_WG_ONLY_K6
 #include "kernels_2d_wg.hip"
 
 #include <cstdio>

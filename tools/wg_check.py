@@ -29,7 +29,7 @@ def time_fn(fn, iters):
     return e0.elapsed_time(e1) / 1e3 / iters
 
 
-def parity(K=6):
+def parity(K=6, base=None):
     rng = np.random.default_rng(11)
     bad = 0
     cases = []
@@ -50,6 +50,8 @@ def parity(K=6):
             if bc == "dirichlet":
                 plan.set_boundary(bc)
             plan.set_option("stream", 1).set_option("steps_per_launch", K)
+            for k, v in (base or {}).items():
+                plan.set_option(k, v)
             for k, v in opts.items():
                 plan.set_option(k, v)
             assert plan.get_option("steps_per_launch") == K, plan.get_option("steps_per_launch")
@@ -93,7 +95,7 @@ def timing(out, iters):
         src = torch.rand(ps, dtype=torch.float64, device="cuda")
         dst = torch.zeros(ps, dtype=torch.float64, device="cuda")
         pts = dims[0] * dims[1]
-        for K, opts in ((4, {}), (6, {}), (6, {"wg_prio": 0}), (6, {"wg_prio": 10}), (6, {"wg_prio": 14}), (6, {"wg_prio": 16}), (6, {"wg_edge_pct": 25}), (6, {"wg_edge_pct": 25, "wg_prio": 0}), (6, {"wg_edge_pct": 35}), (4, {})):
+        for K, opts in ((4, {}), (6, {}), (4, {"wg": 1}), (2, {"wg": 1}), (2, {}), (4, {"wg": 1, "wg_prio": 0}), (4, {"wg": 1, "wg_rows": 400}), (2, {"wg": 1, "wg_rows": 400}), (4, {})):
             plan = L.Plan(shape, dims).set_weights(w)
             plan.set_option("stream", 1).set_option("steps_per_launch", K)
             for k, v in opts.items():
@@ -115,7 +117,7 @@ def main():
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     bad = 0
     if not args.no_parity:
-        bad = parity()
+        bad = parity() + parity(4, {"wg": 1}) + parity(2, {"wg": 1})
         print("parity mismatches:", bad, flush=True)
     if not args.no_timing and bad == 0:
         with open(os.path.join(ROOT, "gpurun_out", "wg_check.jsonl"), "a") as out:
