@@ -274,6 +274,7 @@ void plan_refresh(Plan &p) {
         p.wg_active = p.stream2 && p.boundary == LORA_BC_REFERENCE && p.variant == LORA_VARIANT_DIRECT &&
                       (p.steps_per_launch == 6 || (p.wg == 1 && p.steps_per_launch >= 2)) && p.wg != 0;
         if (p.steps_per_launch == 6 && !p.wg_active) p.steps_per_launch = 4;
+        if (p.wg_active) prepare_2d_wg(p);  // kernel resolution + residency query now, not in the first launch of a run
         p.kernel_name = (p.generic && p.steps_per_launch == 1) ? kernel_name_generic(p)
                         : (p.variant == LORA_VARIANT_MFMA)
                             ? kernel_name_2d_mfma(p)

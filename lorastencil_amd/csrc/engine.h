@@ -131,6 +131,7 @@ int stream_strip_width(int K);
 // K = 6, 4 or 2 applications per launch: workgroup-wide rows, levels pipelined over two groups of waves (kernels_2d_wg.hip)
 hipError_t launch_2d_wg(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s);
 const char *kernel_name_2d_wg(const Plan &p);
+void prepare_2d_wg(const Plan &p);  // one-time host work of the plan's instantiations (no launch)
 int wg_strip_width(int K);
 hipError_t launch_3d(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s);
 // two applications per launch, level 1 in LDS (fp64, reference boundary: level-1 halo = 0)

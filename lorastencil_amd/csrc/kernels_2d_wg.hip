@@ -123,6 +123,7 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
     const int i0 = a.row_begin + chunk * rows;  // first output row of the chunk (interior coordinates)
     const int j0 = strip * a.outw;              // first output column of the strip
     const int row_hi = min(i0 + rows, a.row_end);
+    groups = min(groups, (row_hi - i0 + 7 * K - 1 + 6) / 7);  // the last chunk of a strip may be shorter
     // Can this workgroup's lanes see a column outside the interior at some level?  (rim strips; uniform)
     const bool col_edge = j0 - 3 * K < 0 || j0 + kRowW > a.n;
 
@@ -340,26 +341,37 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// Workgroups of this instantiation that are resident per CU (cached per device).  The first query of an instantiation
+// also makes the runtime load and resolve the kernel -- half a millisecond of host time that lora_plan_create /
+// lora_plan_set_* pay through prepare_2d_wg(), not the first launch of a run.
+template <int EVAL, int KL, int S, int D, int WPS>
+int wg_per_cu(int dev) {
+    static int per_cu[64] = {0};
+    if (dev < 0 || dev >= 64) dev = 0;
+    if (per_cu[dev] == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stencil2d_wg_kernel<EVAL, KL, S, D, WPS>, 256 * S, 0) != hipSuccess || nb < 1) {
+            (void) hipGetLastError();
+            return 1;  // (no device: asked again later)
+        }
+        per_cu[dev] = nb;
+    }
+    return per_cu[dev];
+}
+
 template <int EVAL, int KL, int S, int D, int WPS>
 hipError_t launch_wg_t(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
     constexpr int K = KL * S;
     auto kernel = stencil2d_wg_kernel<EVAL, KL, S, D, WPS>;
-    // one round: as many workgroups as are resident at once
-    static int per_cu[64] = {0};
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     {
         int v = 0;
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
-    if (per_cu[dev] == 0) {
-        int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256 * S, 0) != hipSuccess || nb < 1) {
-            (void) hipGetLastError();
-            nb = 1;
-        }
-        per_cu[dev] = nb;
-    }
+    // one round: as many workgroups as are resident at once
+    const int per_cu_dev = wg_per_cu<EVAL, KL, S, D, WPS>(dev);
+    if (rows_total <= 0) return hipSuccess;  // prepare_2d_wg(): the query above is all that was wanted
     const int lag = 7 * K - 1;  // steps of a chunk beyond its output rows
     auto fit = [&](long rows) {
         long g = (rows + lag + 6) / 7;
@@ -377,7 +389,7 @@ hipError_t launch_wg_t(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
         a.rows_i = fit(p.wg_rows);
     } else {
         // ONE round: the most interior chunks for which every workgroup of the launch is resident at once
-        const long slots = (long) per_cu[dev] * cus;
+        const long slots = (long) per_cu_dev * cus;
         const long min_rows = 4 * lag;  // small grids: a chunk recomputes 7 K - 1 rows, keep that under a quarter
         int best = fit(rows_total);
         for (long c = 1; c <= rows_total; ++c) {
@@ -395,7 +407,7 @@ hipError_t launch_wg_t(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
     a.groups_e = (a.rows_e + lag + 6) / 7;
     a.chunks_i = (rows_total + a.rows_i - 1) / a.rows_i;
     a.chunks_e = (rows_total + a.rows_e - 1) / a.rows_e;
-    a.prio_split = (p.wg_prio != 0 && per_cu[dev] == 2) ? cus : 0;
+    a.prio_split = (p.wg_prio != 0 && per_cu_dev == 2) ? cus : 0;
     a.prio_shift = p.wg_prio > 0 ? p.wg_prio : 12;
     Taps49 w;
     for (int k = 0; k < 49; ++k) w.w[k] = p.w[k];
@@ -462,6 +474,22 @@ hipError_t LORA_WG_ENTRY(const Plan &p, ArgsWG a, int rows_total, hipStream_t s)
 #if LORA_WG_K == 6
 hipError_t launch_2d_wg_k4(const Plan &p, ArgsWG a, int rows_total, hipStream_t s);
 hipError_t launch_2d_wg_k2(const Plan &p, ArgsWG a, int rows_total, hipStream_t s);
+
+// One-time host work of the three instantiations this plan's runs launch (six applications and the four / two of the
+// tails): kernel resolution + the residency query.  No launch; without a device nothing happens.
+void prepare_2d_wg(const Plan &p) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void) hipGetLastError();
+        return;
+    }
+    ArgsWG a{};
+    (void) launch_2d_wg_k6(p, a, 0, nullptr);
+#ifndef LORA_WG_ONLY_K6
+    (void) launch_2d_wg_k4(p, a, 0, nullptr);
+    (void) launch_2d_wg_k2(p, a, 0, nullptr);
+#endif
+}
 
 int wg_strip_width(int K) { return kRowW - 6 * K; }
 
