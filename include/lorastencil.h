@@ -172,8 +172,10 @@ int lora_set_default_boundary(int boundary);
  * BASELINE config 3 asks for 200).  Not reference behaviour.  Returns the previous value. */
 int lora_set_default_normalize(int on);
 /* Integer options.  Results never depend on them except where stated.
- *   steps_per_launch  0 auto / 1 / 2 (2D also 4 with the row-streaming kernel, 3D fp64 also 3 with the plane-streaming
- *                     kernel, 1D also 4, 8, 16, 32) : applications per launch in lora_plan_run (temporal fusion).  1D auto:
+ *   steps_per_launch  0 auto / 1 / 2 (2D also 4 with the row-streaming kernel and 6 with the workgroup-row kernel, 3D fp64
+ *                     also 3 with the plane-streaming kernel, 1D also 4, 8, 16, 32) : applications per launch in
+ *                     lora_plan_run (temporal fusion).  2D auto: 6 (reference boundary; what six leave of a run is covered by
+ *                     one launch of four and / or two); 4 for plain 49-tap tables; 2 under the Dirichlet option.  1D auto:
  *                     the plan's own depth is 8 (lora_plan_stepk, slabs); lora_plan_run uses 16 from 32 sweeps on and
  *                     32 from 64 on
  *   rows_per_thread, panel_width, nt_store, fused_rows, persistent      2D tile shape / block->tile map / stores
@@ -198,6 +200,13 @@ int lora_set_default_normalize(int on);
  *   stream            2D fused launches: 1 = row-streaming kernel (wave-autonomous column strips, kernels_2d_stream.hip),
  *                     0 = tile kernel; stream_rows (output rows per chunk, 0 = auto), stream_depth (2..6 input rows in
  *                     flight per wave), stream_sync (one barrier per 7 rows keeps a workgroup's strips in step)
+ *   wg                2D fused launches through the workgroup-row kernel (kernels_2d_wg.hip: 512-column rows owned by a
+ *                     workgroup, the time levels pipelined over two groups of waves): -1 (default) = in plans that fuse six
+ *                     applications per launch, where it also runs the four- / two-application tails; 0 never; 1 at every
+ *                     depth (6 / 4 / 2).  wg_rows (output rows per chunk; 0 = one round of resident workgroups),
+ *                     wg_edge_pct (how much shorter the chunks of the first / last column strip are, per cent; -1 = 60),
+ *                     wg_prio (log2 of the time slice, in 10 ns ticks, of the alternating wave priorities that share a
+ *                     CU evenly between its two workgroups; 0 = off)
  * ("ablate", the load/store-removing timing experiment of round 1, exists only in -DLORA_DIAGNOSTICS builds of the
  * library; the shipped one answers LORA_EINVAL.)
  * lora_plan_get_option also reads the resolved "tapset", "variant", "fused_eval", "boundary". */
@@ -207,7 +216,7 @@ size_t lora_plan_padded_bytes(const lora_plan *plan);
 /* Name of the kernel a sweep of this plan launches (for matching rocprof rows). */
 const char *lora_plan_kernel_name(const lora_plan *plan);
 /* The same plus every resolved option that selects the kernel instantiation or its launch geometry, e.g.
- * "stencil2d_stream2_kernel[eval=3,depth=4,sync=1,rows=589]": the key measured per-launch HBM traffic is filed under
+ * "stencil2d_wg_kernel[eval=7,k=6,rows=0,edge=-1,prio=12,bc=0]": the key measured per-launch HBM traffic is filed under
  * (profiles/pmc_traffic.json), so that a changed option can never be paired with a stale measurement. */
 const char *lora_plan_kernel_signature(const lora_plan *plan);
 
@@ -222,11 +231,12 @@ int lora_plan_region_granularity(const lora_plan *plan);
 /* TWO kernel applications in one launch (temporal fusion; tiled 2D direct-variant and 3D plans): the intermediate time level
  * lives in LDS and its halo cells are taken as 0 -- the state of the reference driver's second buffer --
  * so d_in must be an even time level (halo = the caller's input halo).  Interior of d_out <- stencil(stencil(d_in)).
- * lora_plan_run uses it when the option "steps_per_launch" is 2. */
+ * lora_plan_run uses it when the plan's resolved "steps_per_launch" is 2 (3D tile / bf16 kernels, 2D under the Dirichlet
+ * option). */
 int lora_plan_step2(lora_plan *plan, const void *d_in, void *d_out, void *stream);
 int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream);
 /* The plan's resolved "steps_per_launch" applications in ONE launch: 1 = lora_plan_step, 2 = lora_plan_step2 (2D / 3D),
- * 4 in 2D, 3 in 3D fp64, 2 / 4 / 8 in 1D (intermediate levels in LDS; halo cells of odd intermediate levels are 0, of even ones the source
+ * 4 / 6 in 2D, 3 in 3D fp64, 2 / 4 / 8 in 1D (intermediate levels in LDS; halo cells of odd intermediate levels are 0, of even ones the source
  * buffer's halo -- the state the step-by-step driver would leave).  d_in must be an even time level.
  * lora_plan_run uses an even number of these and finishes with single sweeps; three-application 3D launches have an
  * odd count and run on the reference's alternating buffer state instead (launch k reads buffer k mod 2, whose halo
@@ -254,10 +264,10 @@ int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *
 typedef struct lora_run_profile {
     int fused_launches;        /* launches of the K-application kernel                               */
     int apps_per_fused_launch; /* K (1 if the plan does not fuse)                                    */
-    int two_launches;          /* tail launches: 2D, K = 4: two applications each; 1D: K/2, K/4 .. 2 */
+    int two_launches;          /* shallower fused launches of the tail: 2D: four and / or two applications; 1D: K/2 .. 2 */
     int single_launches;       /* single-sweep launches (the whole run if K = 1)                     */
     float fused_ms;            /* event time of the K-application launches (+ the halo copy)         */
-    float two_ms;              /* ... of the two-application tail (+ the halo reset)                 */
+    float two_ms;              /* ... of the shallower fused launches (+ the halo reset)             */
     float single_ms;           /* ... of the single-sweep segment                                    */
 } lora_run_profile;
 int lora_plan_run_profiled(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream,

@@ -932,11 +932,21 @@ struct FusedSchedule {
     int tail[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // depths of the n2 launches after the nk full-depth ones
 };
 
+static void drop_graph(lora_plan *plan);
+
+// the scratch grid this plan would use on the current device is there already
+static bool scratch_ready(const lora_plan *plan) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    return plan->scratch && plan->scratch_bytes == lora_plan_padded_bytes(plan) && plan->scratch_device == dev;
+}
+
 static bool ensure_scratch(lora_plan *plan) {
     const size_t bytes = lora_plan_padded_bytes(plan);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return false;
-    if (plan->scratch && plan->scratch_bytes == bytes && plan->scratch_device == dev) return true;
+    if (scratch_ready(plan)) return true;
+    drop_graph(plan);  // a captured run holds the old grid's address
     if (plan->scratch) (void) hipFree(plan->scratch);
     plan->scratch = nullptr;
     if (hipMalloc(&plan->scratch, bytes) != hipSuccess) {
@@ -977,7 +987,7 @@ static FusedSchedule fused_schedule(lora_plan *plan, int times, bool can_fuse, b
             }
         const int n = fs.nk + fs.n2;
         if (n % 2 == 0) return fs;
-        if (n >= 3 && p.use_scratch != 0 && (!allocate || ensure_scratch(plan))) {
+        if (n >= 3 && p.use_scratch != 0 && (allocate ? ensure_scratch(plan) : scratch_ready(plan))) {
             fs.scratch = true;
             return fs;
         }
@@ -1007,7 +1017,7 @@ static FusedSchedule fused_schedule(lora_plan *plan, int times, bool can_fuse, b
             }
         const int n1 = fs.nk + fs.n2;
         if (n1 % 2 == 0) return fs;
-        if (n1 >= 3 && p.use_scratch != 0 && (!allocate || ensure_scratch(plan))) {
+        if (n1 >= 3 && p.use_scratch != 0 && (allocate ? ensure_scratch(plan) : scratch_ready(plan))) {
             fs.scratch = true;
             return fs;
         }
@@ -1031,13 +1041,24 @@ static FusedSchedule fused_schedule(lora_plan *plan, int times, bool can_fuse, b
     }
     const int n = fs.nk + fs.n2;
     if (n % 2 == 0) return fs;
-    if (n >= 3 && p.use_scratch != 0 && (!allocate || ensure_scratch(plan))) {
+    if (n >= 3 && p.use_scratch != 0 && (allocate ? ensure_scratch(plan) : scratch_ready(plan))) {
         fs.scratch = true;
         return fs;
     }
     fs.nk -= 1;  // no scratch grid: an even number of launches instead
     return fs;
 }
+
+// Does lora_plan_run cut this plan's runs into fused launches at all, and is it the three-application 3D schedule (which
+// runs on the reference's own buffer state: no scratch grid)?  One place, used by run_launches and by the pre-capture
+// allocation in lora_plan_run.
+static bool run_can_fuse(const Plan &p) {
+    const int K = p.steps_per_launch;
+    return p.boundary != LORA_BC_PERIODIC && K >= 2 &&
+           (!p.generic || (p.ndim == 2 && p.stream2 && p.boundary == LORA_BC_REFERENCE)) &&
+           ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) || p.ndim == 3 || p.ndim == 1);
+}
+static bool run_is_natural3(const Plan &p) { return run_can_fuse(p) && p.ndim == 3 && p.steps_per_launch == 3; }
 
 struct RunMarks {  // lora_plan_run_profiled: events around the fused and the single-sweep segment
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start | K-launches | 2-launches | singles
@@ -1093,10 +1114,9 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
     }
     int done = 0;
     const int K = p.steps_per_launch;  // applications per fused launch: 2 (2D, 3D) or 2 / 4 / 8 (1D)
-    const bool can_fuse = K >= 2 && (!p.generic || (p.ndim == 2 && p.stream2 && p.boundary == LORA_BC_REFERENCE)) &&
-                          ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) || p.ndim == 3 || p.ndim == 1);
+    const bool can_fuse = run_can_fuse(p);
     FusedSchedule fs;
-    const bool natural3 = can_fuse && p.ndim == 3 && K == 3;
+    const bool natural3 = run_is_natural3(p);
     if (natural3) {
         // Three applications per launch (3D fp64): launch k covers global steps 3 k + 1 .. 3 k + 3, reading buffer
         // k mod 2 and writing the other one -- exactly where the step-by-step driver has these levels, so the launches
@@ -1139,7 +1159,7 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
             mark(1);
         }
     } else {
-        fs = fused_schedule(plan, times, can_fuse);
+        fs = fused_schedule(plan, times, can_fuse, /*allocate=*/!plan->capturing);
     }
     if (fs.nk + fs.n2 > 0) {
         // Temporal fusion.  A fused launch reads a buffer whose halo is the level-0 halo and writes another one, so
@@ -1228,8 +1248,8 @@ int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *
     hipStream_t s = static_cast<hipStream_t>(stream);
     // Launch-bound runs (small grids, many steps: the reference's 1D size sweeps in ~2 us per step) are captured
     // once into a hipGraph and replayed; big grids gain nothing and are launched directly.  Capture needs a real
-    // stream (not the legacy default one), no capture already in progress, and kernels that do no host-side work
-    // at launch (the MFMA variant uploads its band tables).
+    // stream (not the legacy default one) and no capture already in progress; every kernel takes its taps as launch
+    // arguments, so none does host-side work at launch.
     bool want = p.use_graph == 1 || (p.use_graph < 0 && times >= 16 && lora_plan_padded_bytes(plan) <= (64u << 20));
     if (want && s == nullptr) want = false;
     if (want) {
@@ -1245,14 +1265,18 @@ int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *
           plan->graph_times == times && plan->graph_epoch == p.epoch)) {
         drop_graph(plan);
         if (int rc = lora::check_buffers(d_buf0, d_buf1)) return rc;
-        (void) fused_schedule(plan, times, true);  // a scratch grid, if this run wants one, is allocated BEFORE capture
+        // a scratch grid, if this run's schedule wants one, is allocated BEFORE the capture (hipMalloc and the null-stream
+        // memset do not belong inside one); while capturing, run_launches only uses a grid that is already there
+        if (run_can_fuse(p) && !run_is_natural3(p)) (void) fused_schedule(plan, times, true);
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) {
             (void) hipGetLastError();
             return run_launches(plan, d_buf0, d_buf1, times, stream);
         }
+        plan->capturing = true;
         const int rc = run_launches(plan, d_buf0, d_buf1, times, stream);
+        plan->capturing = false;
         e = hipStreamEndCapture(s, &graph);
         if (rc != LORA_OK || e != hipSuccess || !graph) {
             if (graph) (void) hipGraphDestroy(graph);

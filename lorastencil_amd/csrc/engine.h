@@ -174,6 +174,7 @@ struct lora_plan {
     void *graph_buf[2] = {nullptr, nullptr};
     int graph_times = -1;
     unsigned graph_epoch = 0;  // value of p.epoch the graph was captured at
+    bool capturing = false;    // lora_plan_run is capturing its launches: no allocations meanwhile
     // one more padded grid, allocated on first need (lora_plan_run with an odd number of fused launches)
     void *scratch = nullptr;
     size_t scratch_bytes = 0;

@@ -1,4 +1,6 @@
-// kernels_2d_stream.hip -- TWO kernel applications of a radius-3 2D stencil per launch, row-streaming form.
+// kernels_2d_stream.hip -- FOUR (or two) kernel applications of a radius-3 2D stencil per launch, row-streaming form.
+// (Round 3: the default for 2D is now kernels_2d_wg.hip -- six applications, workgroup-wide rows; this kernel serves
+// plans that ask for four or two applications per launch, the slab drivers, and the Dirichlet option.)
 //
 // The tile kernel of kernels_2d_fused.hip holds a whole 46 x 136 input window in LDS per workgroup: 50 KB, three
 // workgroups per CU, and inside a workgroup strictly serial phases (window load -> barrier -> application 1 ->
@@ -8,27 +10,29 @@
 // are tile bookkeeping (clamped addresses, guards).
 //
 // Here every WAVE is autonomous and walks DOWN a column strip (the time-step loop of the reference driver,
-// 2d/gpu.cu:544-546, two steps per pass; kernel replaced: 2d/gpu.cu:181-273):
-//   * a strip is 116 output columns = 122 intermediate columns = 128 input columns: exactly one 16-byte piece per
-//     lane and row, so a row of the strip is ONE global_load_lds_dwordx4 (1 KiB, global -> LDS, no staging
-//     registers) and one buffer_store_dwordx4;
+// 2d/gpu.cu:544-546, K = 2 or 4 steps per pass; kernel replaced: 2d/gpu.cu:181-273):
+//   * a strip is 128 input columns = 128 - 3 l columns of level l = 128 - 6 K output columns (116 for K = 2, 104 for
+//     K = 4): exactly one 16-byte piece per lane and row, so a row of the strip is ONE global_load_lds_dwordx4 (1 KiB,
+//     global -> LDS, no staging registers) and one buffer_store_dwordx4;
 //   * the scatter form of apply_row needs each input row once: LDS only serves as the cross-lane window exchange of
 //     the row being consumed (4 x ds_read_b128 per row and level, as in the tile kernel), so a wave owns a ring of
-//     seven 1 KiB input-row slots (rows in flight) plus one intermediate row: 8.3 KB per wave, 16 waves per CU;
+//     seven (K = 2) or ten (K = 4) 1 KiB input-row slots (rows in flight, and the halo source rows of level 2) plus one
+//     row buffer per intermediate level: 8.3 / 13.3 KB per wave, 16 / 12 waves per CU;
 //   * the seven partially summed rows of each level live in rotating register files (the loop is unrolled by 7 so
-//     that the rotation is a compile-time renaming, apply_row<.., ROT>);
+//     that the rotation is a compile-time renaming, apply_row<.., ROT>): 76 VGPRs at K = 2, 130 at K = 4;
 //   * no workgroup barriers on the data path: a wave's own LDS traffic is ordered by the hardware, loads run D rows
 //     ahead of the row being consumed, and the vector-memory counter is hand-counted: "row r has landed" is
 //     s_waitcnt vmcnt(D - 1) -- only the D - 1 younger LOADS may be outstanding (the compiler cannot see the
 //     dependence between an LDS-DMA and a later ds_read; stores of rows that do not exist go through an empty buffer
 //     descriptor, so the instruction stream has no branches);
-//   * recomputed halo: 12 input rows and 6 intermediate rows per CHUNK of several hundred rows instead of per
-//     34-row tile; the 12 shared columns of neighbouring strips are read by neighbouring waves of one workgroup at
-//     about the same time (optionally kept in step by one s_barrier per 7 rows) and hit in L1 / L2.
+//   * recomputed halo: 7 K - 1 steps per CHUNK of several hundred rows instead of per 34-row tile; the 6 K shared
+//     columns of neighbouring strips are read by neighbouring waves of one workgroup at about the same time
+//     (optionally kept in step by one s_barrier per 7 rows) and hit in L1 / L2.
 //
-// Semantics are those of the tile kernel (two consecutive launches of the reference driver from an even step,
-// SURVEY B1/B2): the intermediate level's cells outside the interior are 0 (or, under the Dirichlet option, keep the
-// input halo value); per accumulator the taps arrive in the same order, so results are bit-identical to it.
+// Semantics are those of K consecutive launches of the reference driver from an even step: cells of an
+// intermediate level outside the interior are 0 at odd levels and the source buffer's own halo value at even ones (under
+// the Dirichlet option, K = 2, the input halo value); per accumulator the taps arrive in the same order as in the tile
+// kernel, so results are bit-identical to it.
 #include <hip/hip_runtime.h>
 
 #include "device_common.h"
@@ -72,16 +76,19 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // spill 370 VGPRs of the rotating accumulators.  LDS address = M0 + 16 x lane.
 __device__ __forceinline__ void dma_piece_masked(const double *gptr, unsigned lds_byte_addr, unsigned long long mask) {
     unsigned long long saved;
+    unsigned saved_m0;  // M0 is the compiler's (a reserved register: it may not be named as clobbered) -- saved and restored here
     asm volatile(
         "s_mov_b64 %0, exec\n\t"
-        "s_mov_b64 exec, %1\n\t"
-        "s_mov_b32 m0, %2\n\t"
+        "s_mov_b32 %1, m0\n\t"
+        "s_mov_b64 exec, %2\n\t"
+        "s_mov_b32 m0, %3\n\t"
         "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, off\n\t"
+        "global_load_lds_dwordx4 %4, off\n\t"
+        "s_mov_b32 m0, %1\n\t"
         "s_mov_b64 exec, %0"
-        : "=&s"(saved)
+        : "=&s"(saved), "=&s"(saved_m0)
         : "s"(mask), "s"(lds_byte_addr), "v"(gptr)
-        : "memory", "m0");
+        : "memory");
 }
 
 // Step r of a chunk whose first output row is i0 consumes input row i0 - 3 K + r and completes, for l = 1..K, the

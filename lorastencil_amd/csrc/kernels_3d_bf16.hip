@@ -298,10 +298,9 @@ __global__ __launch_bounds__(256, (CPL == 4 ? 4 : 3)) void stencil3d_bf16_kernel
 // 5 workgroups per CU that is ~47 KB per CU against a loaded HBM latency of ~4 us, i.e. ~4 TB/s -- exactly where it
 // sits (PMC), whatever the FMA count.  Here the planes travel global -> LDS directly (global_load_lds_dwordx4, no
 // staging registers) into a 3-slot ring, TWO planes ahead of the one being consumed.  LDS-DMA completion is only
-// ordered by the issuing wave's vmcnt, so the waits are hand-counted: every iteration issues exactly NIT DMA
-// instructions and RY buffer stores (stores of planes that do not exist go through an empty descriptor and are
-// dropped by the range check), which makes "plane p has landed" the constant s_waitcnt vmcnt(2 RY + NIT); a raw
-// s_barrier (not __syncthreads, which would drain vmcnt(0)) then publishes every wave's part of the plane.
+// ordered by the issuing wave's vmcnt, so the waits are hand-counted -- over the LOADS only: "plane p has landed" is
+// s_waitcnt vmcnt(NIT), the pieces of plane p + 1 being the only younger loads (see consume()); a raw s_barrier (not
+// __syncthreads, which would drain vmcnt(0)) then publishes every wave's part of the plane.
 // ---------------------------------------------------------------------------------------------------------------
 template <int TAPSET, int RY>
 __global__ __launch_bounds__(256, 4) void stencil3d_bf16_ring_kernel(const Args3Dh a, const Taps27f W) {
@@ -372,16 +371,15 @@ __global__ __launch_bounds__(256, 4) void stencil3d_bf16_ring_kernel(const Args3
 
     auto consume = [&](int p, auto phase_tag) {
         constexpr int PHASE = decltype(phase_tag)::value;  // = p mod 3 = ring slot of plane p
-        // younger operations than plane p's DMA: NIT (plane p+1) for p = 0; + RY stores for p = 1; 2 RY + NIT in
-        // steady state; 2 RY for the last plane (no plane p+1 was requested)
-        if (p == 0)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT) : "memory");
-        else if (p == 1)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT + RY) : "memory");
-        else if (p == nplanes - 1)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RY) : "memory");
+        // "plane p has landed": count LOADS only.  The loads younger than plane p's DMA are the NIT pieces of plane p + 1
+        // (none for the last plane); loads complete in order among themselves, so with at most NIT operations outstanding
+        // plane p is complete.  Counting the interleaved stores as well (vmcnt(2 RY + NIT), the first version of this
+        // kernel) assumes a younger store never completes before an older LDS-DMA load: the same assumption gave a wrong
+        // plane about once in 400 runs in kernels_3d_bf16_mfma.hip (tools/stress_bf16_mfma.py).
+        if (p == nplanes - 1)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * RY + NIT) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NIT) : "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (p + 2 < nplanes) issue_plane(p + 2, (PHASE + 2) % 3);  // slot of plane p-1: every wave is done with it

@@ -37,6 +37,11 @@
 // multiply-adds per point): identical while every partial sum is an exact integer, ~1e-16 relative per sweep otherwise.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -728,15 +733,20 @@ hipError_t launch_stream3(const Plan &p, const double *in, double *out, const do
     constexpr size_t lds = ASYNC ? stream3_async_lds_bytes<K, NW>() : stream3_lds_bytes<K, NW, NS ? NS : 2, PIPE>();
     static_assert(lds <= (NW == 4 ? 80 : 160) * 1024, "LDS budget");
     auto go = [&](auto kernel) -> hipError_t {
-        // per instantiation and device: more than 64 KiB of dynamic LDS has to be asked for once
-        static unsigned long long prepared = 0;
+        // per KERNEL and device: more than 64 KiB of dynamic LDS has to be asked for once.  (Keyed by the kernel's address:
+        // the two boundary variants have the same function-pointer type and therefore share this lambda's statics.)
+        static std::mutex mu;
+        static std::vector<std::pair<const void *, int>> prepared;
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-        if (dev >= 64 || !(prepared >> dev & 1ull)) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-            if (e != hipSuccess) return e;
-            if (dev < 64) prepared |= 1ull << dev;
+        {
+            const std::pair<const void *, int> key(reinterpret_cast<const void *>(kernel), dev);
+            std::lock_guard<std::mutex> lock(mu);
+            if (std::find(prepared.begin(), prepared.end(), key) == prepared.end()) {
+                const hipError_t e = hipFuncSetAttribute(key.first, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+                if (e != hipSuccess) return e;
+                prepared.push_back(key);
+            }
         }
         hipLaunchKernelGGL(kernel, dim3((unsigned) nblocks), dim3(NW * 64), lds, s, a, w);
 #ifdef LORA_DIAGNOSTICS

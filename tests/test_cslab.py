@@ -85,7 +85,7 @@ def test_loopback_slabs_equal_single_gpu(L, shape, dims, nranks, times, every, f
     exp = O.run(shape, a, times)
     if a.ndim == 1:
         exp[-1] = out[-1]
-    if np.abs(exp).max() < 2.0 ** 53:
+    if np.abs(exp).max() < 2.0 ** 50:
         assert np.array_equal(out, exp)
     else:
         assert np.abs(out - exp).max() <= 1e-13 * np.abs(exp).max()
