@@ -340,12 +340,37 @@ void plan_refresh(Plan &p) {
         }
         p.stream3_active = stream3 ? 1 : 0;
         p.sep64_valid = (stream3 && sep_ok) ? 1 : 0;
-        if (p.sep64_valid)
+        // FOUR applications per launch with the levels in registers (kernels_3d_lanes.hip): fp64, the 7-point star or
+        // exactly separable box taps, reference boundary, any extents (odd innermost ones too: its fused launches replace
+        // the one-thread-per-point fallback, which then only serves single-sweep tails).  Big grids: a tile is 24 x 120
+        // output points and a z-chunk re-reads 8 planes, so the launch wants ~256 tiles x long chunks (star3d1r
+        // GStencils/s per launch, planes kernel / this one: see DESIGN 3.3d); option lanes3 = 1 / 0 forces either,
+        // steps_per_launch = 4 asks for it by itself.
+        double cba64l[9];
+        const bool lanes_taps = p.dtype != LORA_BF16 && p.boundary == LORA_BC_REFERENCE &&
+                                (p.tapset == TAPS3D_STAR ||
+                                 (p.tapset == TAPS3D_BOX && p.separable != 0 && separable_27d(p.w, cba64l) != 0));
+        bool lanes = false;
+        if (lanes_taps && p.lanes3 != 0 && p.steps_per_launch_req != 1 && p.steps_per_launch_req != 2 &&
+            p.steps_per_launch_req != 3)
+            lanes = p.steps_per_launch_req == 4 || p.lanes3 == 1 || npts >= 6.0e7;
+        p.lanes3_active = lanes ? 1 : 0;
+        if (lanes) {
+            p.steps_per_launch = 4;
+            p.stream3_active = 0;
+            if (p.tapset == TAPS3D_BOX) {
+                p.sep64_valid = 1;
+                for (int k = 0; k < 9; ++k) p.sep64[k] = cba64l[k];
+            }
+            prepare_3d_lanes(p);
+        }
+        if (p.sep64_valid && !lanes)
             for (int k = 0; k < 9; ++k) p.sep64[k] = cba64[k];
         p.kernel_name = (p.dtype == LORA_BF16)
                             ? (p.steps_per_launch == 2 ? (p.variant == LORA_VARIANT_MFMA ? kernel_name_3d_bf16_mfma2(p)
                                                                                           : kernel_name_3d_bf16_fused2(p))
                                                        : kernel_name_3d_bf16(p))
+                        : lanes                ? kernel_name_3d_lanes(p)
                         : p.generic            ? kernel_name_generic(p)
                         : p.steps_per_launch >= 2 ? (stream3 ? kernel_name_3d_stream(p) : kernel_name_3d_fused2(p))
                                                   : kernel_name_3d(p);
@@ -625,6 +650,9 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "stream3")) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.stream3 = value;
+    } else if (!std::strcmp(key, "lanes3")) {
+        if (value < -1 || value > 1) return LORA_EINVAL;
+        p.lanes3 = value;
     } else if (!std::strcmp(key, "stream3_waves")) {
         if (value != 0 && value != 4 && value != 8) return LORA_EINVAL;
         p.stream3_waves = value;
@@ -675,12 +703,13 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "steps_per_launch")) {
         const bool three = value == 3 && p.ndim == 3 && p.dtype != LORA_BF16;  // 3D fp64 plane-streaming kernel
         const bool six = value == 6 && p.ndim == 2;                             // 2D workgroup-row kernel
+        const bool four3 = value == 4 && p.ndim == 3 && p.dtype != LORA_BF16;  // 3D fp64 register-resident kernel
         if (value < 0 || value > 32 || ((value & (value - 1)) && !three && !six)) return LORA_EINVAL;  // 0 (auto), 1, 2, 4, 8, 16, 32
         if (value > 8 && p.ndim != 1) return LORA_EUNSUPPORTED;  // 16 and 32 exist in 1D only
         const bool fusable = (p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && (!p.generic || p.stream2)) ||
-                             (p.ndim == 3 && !p.generic) || p.ndim == 1;
+                             (p.ndim == 3 && (!p.generic || four3)) || p.ndim == 1;
         if (value >= 2 && !fusable) return LORA_EUNSUPPORTED;
-        if (value > 2 && p.ndim == 3 && !three) return LORA_EUNSUPPORTED;  // 3D: two; three in the fp64 plane-streaming kernel
+        if (value > 2 && p.ndim == 3 && !three && !four3) return LORA_EUNSUPPORTED;  // 3D: two; three (plane-streaming) or four (register-resident) in fp64
         if (value > 4 && p.ndim == 2 && !six) return LORA_EUNSUPPORTED;  // 2D: two, four (row-streaming kernel), six (workgroup rows)
         p.steps_per_launch_req = value;
     } else if (!std::strcmp(key, "fused_pipeline")) {
@@ -788,6 +817,9 @@ const char *lora_plan_kernel_signature(const lora_plan *plan) {
                       p.panel_width);
     else if (k == "stencil2d_mfma_kernel")
         std::snprintf(buf, sizeof buf, "rank=%d,panel=%d", p.lowrank.rank, p.panel_width);
+    else if (k == "stencil3d_lanes_kernel")
+        std::snprintf(buf, sizeof buf, "taps=%d,k=%d,fzc=%d,bc=%d", p.sep64_valid ? 2 : p.tapset, p.steps_per_launch, p.fused_z_chunk,
+                      p.boundary);
     else if (k == "stencil3d_planes_kernel")
 {
         const int K = p.steps_per_launch, pipe = (K == 2 || p.stream3_pipe) ? 1 : 0;
@@ -828,6 +860,17 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
     const bool ok2 = p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT &&
                      (!p.generic || (p.stream2 && p.boundary == LORA_BC_REFERENCE));
     const bool ok3 = p.ndim == 3 && !p.generic;
+    if (p.ndim == 3 && p.lanes3_active) {  // the two-application tail of a four-application plan (also: odd innermost extents)
+        if (int rc = lora::check_buffers(d_in, d_out)) return rc;
+        if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
+        const hipError_t e = lora::launch_3d_lanes(p, 2, static_cast<const double *>(d_in), static_cast<double *>(d_out), begin,
+                                                   end, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) {
+            lora::set_last_error("fused register-resident 3D kernel launch", e);
+            return LORA_EHIP;
+        }
+        return LORA_OK;
+    }
     if (!ok2 && !ok3) return LORA_EUNSUPPORTED;
     if (int rc = lora::check_buffers(d_in, d_out)) return rc;
     if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
@@ -904,6 +947,17 @@ int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int b
         }
         return LORA_OK;
     }
+    if (p.ndim == 3 && p.lanes3_active && (p.steps_per_launch == 4 || p.steps_per_launch == 2)) {
+        if (int rc = lora::check_buffers(d_in, d_out)) return rc;
+        if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
+        const hipError_t e = lora::launch_3d_lanes(p, p.steps_per_launch, static_cast<const double *>(d_in),
+                                                   static_cast<double *>(d_out), begin, end, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) {
+            lora::set_last_error("fused register-resident 3D kernel launch", e);
+            return LORA_EHIP;
+        }
+        return LORA_OK;
+    }
     if (p.ndim == 3 && p.steps_per_launch == 3)  // an even global step: level 1 has the zero halo, level 2 the source's
         return lora::step3_natural(p, d_in, d_out, d_in, 0, begin, end, stream);
     if (p.ndim != 1) return lora_plan_step2_region(plan, d_in, d_out, begin, end, stream);
@@ -968,8 +1022,8 @@ static FusedSchedule fused_schedule(lora_plan *plan, int times, bool can_fuse, b
     if (!can_fuse || K < 2) return fs;
     fs.nk = times / K;
     fs.n2 = 0;
-    if (p.ndim == 2) {
-        // 2D: what the full-depth launches leave is covered by one launch of four and / or one of two applications (the
+    if (p.ndim == 2 || (p.ndim == 3 && K == 4)) {
+        // 2D (and 3D with four applications per launch): what the full-depth launches leave is covered by one launch of four and / or one of two applications (the
         // row-streaming kernel), so that at most one single sweep remains: 100 sweeps at depth 6 = 16 x 6 + 4
         int r = times - K * fs.nk;
         if (K == 6 && r >= 2 && r < 4 && fs.nk >= 1) {
@@ -1055,7 +1109,7 @@ static FusedSchedule fused_schedule(lora_plan *plan, int times, bool can_fuse, b
 static bool run_can_fuse(const Plan &p) {
     const int K = p.steps_per_launch;
     return p.boundary != LORA_BC_PERIODIC && K >= 2 &&
-           (!p.generic || (p.ndim == 2 && p.stream2 && p.boundary == LORA_BC_REFERENCE)) &&
+           (!p.generic || (p.ndim == 2 && p.stream2 && p.boundary == LORA_BC_REFERENCE) || (p.ndim == 3 && p.lanes3_active)) &&
            ((p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT) || p.ndim == 3 || p.ndim == 1);
 }
 static bool run_is_natural3(const Plan &p) { return run_can_fuse(p) && p.ndim == 3 && p.steps_per_launch == 3; }

@@ -89,6 +89,8 @@ struct Plan {
     int stream3_pipe = 0;     // 3D plane-streaming kernel: 1 = every level consumes what was published one step earlier (one barrier per step, two buffers per level)
     int stream3_async = 0;    // 3D plane-streaming kernel: 1 = no workgroup barriers (neighbour-wave counters in LDS, private input rings)
     int stream3_slots = 0;    // 3D plane-streaming kernel: input plane slots of the LDS ring (0 = as many as fit)
+    int lanes3 = -1;          // 3D fp64 fused launches through the register-resident kernel (kernels_3d_lanes.hip: four applications per launch): -1 by grid size, 0 never, 1 always (star / separable box taps, reference boundary)
+    int lanes3_active = 0;    // resolved
     int fused_z_chunk = 0;    // 3D fused: output planes per workgroup (0 = auto: 32, shorter on small grids)
     int steps_per_launch_req = 0;  // 0 = auto, 1, 2 (2D / 3D), 4 (2D row-streaming kernel), 2 / 4 / 8 (1D)
     int steps_per_launch = 1;      // resolved
@@ -140,6 +142,10 @@ const char *kernel_name_3d_fused2(const Plan &p);
 hipError_t launch_3d_stream(const Plan &p, int K, const double *in, double *out, const double *halo_src, int parity,
                             int begin, int end, hipStream_t s);
 const char *kernel_name_3d_stream(const Plan &p);
+// K = 4 (or 2) applications per launch with the levels in registers (star / exactly separable box taps, fp64, any extents)
+hipError_t launch_3d_lanes(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s);
+const char *kernel_name_3d_lanes(const Plan &p);
+void prepare_3d_lanes(const Plan &p);
 int stream3_slots(int K, int waves, int pipe, int requested);
 int stream3_waves(const Plan &p, int K, int pipe);
 // any size, any taps (odd innermost extents): one thread per point

@@ -1,0 +1,349 @@
+// kernels_3d_lanes.hip -- FOUR applications of a 3D radius-1 stencil per launch (fp64), the time levels held in registers.
+//
+// Where round 2 left 3D (profiles/r02_star3d1r_pmc.json): the plane-streaming kernel of
+// kernels_3d_planes.hip keeps every level as a 66 x 68 tile in LDS.  Four tiles are 142 KB, so it stops at three
+// applications per launch and one 8-wave workgroup per CU; per level a wave reads 18 x 16-byte windows and writes 4 to
+// compute 56 multiply-adds, and with K barriers per plane all eight waves read, then compute, then write -- the LDS pipe
+// (992 cycles per level and CU, 42 % of them the 79 B/clk ds_write_b128 path) and the vector pipe (448) take turns:
+// ~6500 cycles per plane step where neither pipe needs 3000.  And at three applications per launch with 1.2 x read
+// amplification the launch would hit the HBM ceiling near 750 GStencils/s anyway.
+//
+// Here a level never goes to LDS as a tile:
+//   * A lane owns the same 4 rows x 2 columns of a (4 NW) x 128 tile at EVERY level.  x-neighbours are the neighbouring
+//     lanes' registers (v_mov_b32_dpp wave_shr:1 / wave_shl:1: 4 moves per row and level, each at the issue cost of one
+//     fp64 multiply-add -- tools/probes/dpp_rate_probe.hip); y-neighbours are the lane's own rows, and across waves the
+//     two edge rows each wave publishes per level (2 ds_write_b128 + 2 ds_read_b128 per wave and level instead of 4 + 18);
+//     z is streamed: per level and point two partial sums live between steps (the plane above has its dz = 0 tap, the
+//     plane at hand its dz = 0 and dz = 1 taps), the third is completed in the step and becomes the next level's input.
+//   * So K = 4 fits: 4 x 32 partial-sum registers + planes in flight = 236 VGPRs, two waves per SIMD, 64 KB of LDS.
+//     The grid is read once and written once per FOUR sweeps (4 B per point and sweep compulsory).
+//   * Per accumulator the taps arrive in the oracle's order (dz, then dy, then dx): bit-identical to four single sweeps
+//     (and to the other fused 3D kernels), also for the separable box (x-pass, y-pass, z-scatter as in planes_3d.h).
+//   * Input planes come straight into registers (4 x global_load_dwordx4 per lane and plane), one plane ahead; the plane
+//     completed in a step is stored at the START of the next one, right behind the step's single s_waitcnt vmcnt(0) --
+//     everything that wait covers (the loads of this step's plane, the stores of the plane before) was issued a whole
+//     step earlier.
+//   * Halo semantics as in 2D: cells of an intermediate level outside the interior are 0 at odd levels and the
+//     source buffer's own halo value at even ones (level 2).  Tiles on the grid's rim, and every tile in the few steps
+//     whose planes lie outside the z range, run an EDGE copy of the step that forces them.  The level-2 value of a cell is
+//     the input's value of the same cell two planes back in the stream -- a cell the lane itself loaded two steps earlier:
+//     it comes out of a private three-plane delay line in LDS (4 ds_write_b128 + 4 ds_read_b128 per step; fetching it
+//     again by LDS-DMA cost four ~100-cycle instruction issues per step and made rim tiles a third slower).
+//   * One round: tiles x z-chunks = the workgroups resident at once (one per CU), chunks as long as that allows.
+//   * Odd innermost extents: rows are then only 8-byte aligned, which 16-byte global loads tolerate; the stores go through
+//     a buffer descriptor whose range check cuts the half-valid last pair (the 2D kernels' trick).
+//
+// Taps: the 7-point star (any weights) and exactly separable 27-point boxes (the reference's); other 27-tap tables stay
+// with kernels_3d_planes.hip / kernels_3d_fused.hip.  Replaces the reference's z-loop 3d/gpu_star.cu:101-133 /
+// gpu_box.cu:105-140 and time-step loop 3d/gpu_star.cu:177-181 (four steps per pass).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+
+#include "device_common.h"
+
+namespace lora {
+
+namespace {
+
+constexpr int kTileW = 128;  // columns of a tile: 64 lanes x 2
+constexpr int kOutW = 120;   // output columns of a tile: lanes 2 .. 61 (K <= 4 columns lost per side, pairs kept whole)
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+struct ArgsL3 {
+    const double *in;
+    double *out;
+    int h, m, n;
+    int ld;
+    long plane;
+    int z_begin, z_end;
+    int zc;
+    int tiles_x, tiles_y;
+};
+
+__device__ __forceinline__ double lane_below(double v) {  // the value lane i - 1 holds (0 in lane 0)
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int) b, 0x138, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), 0x138, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long) hi << 32) | (unsigned) lo);
+}
+__device__ __forceinline__ double lane_above(double v) {  // the value lane i + 1 holds (0 in lane 63)
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int) b, 0x130, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), 0x130, 0xf, 0xf, true);
+    return __builtin_bit_cast(double, ((long long) hi << 32) | (unsigned) lo);
+}
+
+// Step p of a chunk whose first output plane is k0 takes input plane k0 - K + p; level l completes its plane
+// k0 - K + p - l in that step (one plane behind the level below); level K is the output, stored in step p + 1.
+template <int TAPSET, int K, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL3 a, const Taps27 W) {
+    constexpr int OH = 4 * NW - 2 * K;  // output rows of a tile
+    static_assert(K == 2 || K == 4, "an even number of applications (fused launches start at even steps)");
+    static_assert(TAPSET == TAPS3D_STAR || TAPSET == TAPS3D_SEP, "star or separable box");
+    __shared__ __attribute__((aligned(16))) double edge_rows[K][NW][2][kTileW];  // level l: each wave's first / last row
+    __shared__ __attribute__((aligned(16))) double delay[K > 2 ? 3 : 1][NW][4][kTileW];  // EDGE: this wave's input planes of the last three steps
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int per_chunk = a.tiles_x * a.tiles_y;
+    const int chunk = lin / per_chunk;
+    const int rem = lin - chunk * per_chunk;
+    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    const int k0 = a.z_begin + chunk * a.zc;
+    const int zc = min(a.zc, a.z_end - k0);
+    const int X0 = tx * kOutW - 4, Y0 = ty * OH - K;  // interior coordinates of the tile's first column / row
+    // this lane's cells: rows Y0 + 4 wv + r (r = 0 .. 3), columns X0 + 2 lane, + 1; padded: + 2 rows, + 4 columns, clamped
+    // into the padded array (clamped cells only feed cells outside the interior, which EDGE forces, or nothing)
+    const int col = X0 + 2 * lane;
+    const int pc = min(max(col + 4, 0), a.n + 6);
+    long rowoff[4];  // uniform: padded row x ld
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rowoff[r] = (long) min(max(Y0 + 4 * wv + r + 2, 0), a.m + 3) * a.ld;
+    const int up = max(wv - 1, 0), dn = min(wv + 1, NW - 1);  // (the tile's outermost rows are never valid beyond level 0)
+
+    // stores: lanes 2 .. 61 write interior columns col, col + 1 of rows K .. 4 NW - K - 1 of the tile; the descriptor's
+    // range check drops what lies beyond the row (also the second half of the last pair when n is odd)
+    const unsigned st_off = (lane >= 2 && lane < 62 && col >= 0) ? 8u * (unsigned) col : 0x80000000u;
+    bool st_row[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int trow = 4 * wv + r;
+        st_row[r] = trow >= K && trow < 4 * NW - K && Y0 + trow < a.m;
+    }
+
+    // EDGE: which of this lane's cells are interior cells in x and y
+    bool in0[4], in1[4];
+    const bool xy_rim = X0 < 0 || X0 + kTileW > a.n || Y0 < 0 || Y0 + 4 * NW > a.m;  // (uniform over the workgroup)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = Y0 + 4 * wv + r;
+        const bool row_in = (unsigned) row < (unsigned) a.m;
+        in0[r] = row_in && (unsigned) col < (unsigned) a.n;
+        in1[r] = row_in && (unsigned) (col + 1) < (unsigned) a.n;
+    }
+
+    double a1[K][4][2], a0[K][4][2];  // per level: the plane at hand (dz = 0, 1 taps in) / the plane above (dz = 0 tap in)
+#pragma unroll
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a1[l][r][0] = a1[l][r][1] = a0[l][r][0] = a0[l][r][1] = 0.0;
+    d2 nxt[4], outv[4];
+    auto load_plane = [&](int p) {
+        const double *src = a.in + (long) min(max(k0 - K + p + 1, 0), a.h + 1) * a.plane + pc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nxt[r] = *reinterpret_cast<const d2 *>(src + rowoff[r]);  // (compiler-tracked: see step())
+    };
+    load_plane(0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) outv[r] = (d2){0.0, 0.0};
+
+    auto step = [&](const int p, auto edge_tag) {
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        // Everything issued one step ago has had a whole step to complete: the loads of plane p (and of its halo values), the
+        // stores of the output plane before last.  The plane loads are plain loads on purpose: the compiler waits for them
+        // where they are first used -- right here, and with stores outstanding beside them it waits for vmcnt(0), which is
+        // what this step wants anyway -- and it never copies or spills a register whose load is still in flight (loads
+        // issued and waited for in separate asm statements gave wrong planes at 256 VGPRs).  The explicit wait is for the
+        // LDS-DMA of the halo values, whose consumers (ds_read) the compiler does not connect to it.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        {
+            const int o = p - 2 * K - 1;  // the output plane completed in the previous step
+            const bool live = o >= 0 && o < zc;
+            double *const dst = a.out + (long) (k0 + max(o, 0) + 1) * a.plane + 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                    dst + rowoff[r], 0, (live && st_row[r]) ? (unsigned) a.n * 8u : 0u, 0x00020000);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outv[r]), rs, st_off, 0, 0);
+            }
+        }
+        double v[4][2];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v[r][0] = nxt[r].x;
+            v[r][1] = nxt[r].y;
+        }
+        load_plane(p + 1);
+        if (EDGE && K > 2) {
+            // The value a level-2 cell outside the interior is forced to is the source buffer's own value there (while fused
+            // launches run every buffer carries buffer 0's halo) -- the very cell this lane holds of the INPUT plane with the
+            // same index, which it took in two steps ago: a private delay line of three planes in LDS, no memory request.
+#pragma unroll
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<d2 *>(&delay[p % 3][wv][r][2 * lane]) = (d2){v[r][0], v[r][1]};
+        }
+#pragma unroll
+        for (int l = 0; l < K; ++l) {
+            // level l + 1 from the plane of level l in v.  Rows above / below this wave's four: the neighbours' edge rows.
+            *reinterpret_cast<d2 *>(&edge_rows[l][wv][0][2 * lane]) = (d2){v[0][0], v[0][1]};
+            *reinterpret_cast<d2 *>(&edge_rows[l][wv][1][2 * lane]) = (d2){v[3][0], v[3][1]};
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            const d2 vu = *reinterpret_cast<const d2 *>(&edge_rows[l][up][1][2 * lane]);
+            const d2 vd = *reinterpret_cast<const d2 *>(&edge_rows[l][dn][0][2 * lane]);
+            double nv[4][2];
+            if constexpr (TAPSET == TAPS3D_STAR) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double xl = lane_below(v[r][1]), xr = lane_above(v[r][0]);
+                    const double u0 = r == 0 ? vu.x : v[r - 1][0], u1 = r == 0 ? vu.y : v[r - 1][1];
+                    const double b0 = r == 3 ? vd.x : v[r + 1][0], b1 = r == 3 ? vd.y : v[r + 1][1];
+                    // the dz = 2 tap completes the plane below; the dz = 1 taps in (dy, dx) order go to the plane at hand;
+                    // the dz = 0 tap opens the plane above (fma with a literal zero: what adding to a cleared sum gives)
+                    nv[r][0] = fma(W.w[22], v[r][0], a1[l][r][0]);
+                    nv[r][1] = fma(W.w[22], v[r][1], a1[l][r][1]);
+                    double s0 = fma(W.w[10], u0, a0[l][r][0]), s1 = fma(W.w[10], u1, a0[l][r][1]);
+                    s0 = fma(W.w[12], xl, s0);
+                    s1 = fma(W.w[12], v[r][0], s1);
+                    s0 = fma(W.w[13], v[r][0], s0);
+                    s1 = fma(W.w[13], v[r][1], s1);
+                    s0 = fma(W.w[14], v[r][1], s0);
+                    s1 = fma(W.w[14], xr, s1);
+                    a1[l][r][0] = fma(W.w[16], b0, s0);
+                    a1[l][r][1] = fma(W.w[16], b1, s1);
+                    a0[l][r][0] = fma(W.w[4], v[r][0], 0.0);
+                    a0[l][r][1] = fma(W.w[4], v[r][1], 0.0);
+                }
+            } else {
+                // separable taps w = a(z) b(y) c(x), W.w[0..2] = c, [3..5] = b, [6..8] = a (planes_3d.h, scatter_plane_sep):
+                // x-pass over the six rows, y-pass, then the three z contributions
+                double t0[6], t1[6];
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const double c0 = j == 0 ? vu.x : (j == 5 ? vd.x : v[j - 1][0]);
+                    const double c1 = j == 0 ? vu.y : (j == 5 ? vd.y : v[j - 1][1]);
+                    const double xl = lane_below(c1), xr = lane_above(c0);
+                    t0[j] = fma(W.w[2], c1, fma(W.w[1], c0, W.w[0] * xl));
+                    t1[j] = fma(W.w[2], xr, fma(W.w[1], c1, W.w[0] * c0));
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double u0 = fma(W.w[5], t0[r + 2], fma(W.w[4], t0[r + 1], W.w[3] * t0[r]));
+                    const double u1 = fma(W.w[5], t1[r + 2], fma(W.w[4], t1[r + 1], W.w[3] * t1[r]));
+                    nv[r][0] = fma(W.w[8], u0, a1[l][r][0]);
+                    nv[r][1] = fma(W.w[8], u1, a1[l][r][1]);
+                    a1[l][r][0] = fma(W.w[7], u0, a0[l][r][0]);
+                    a1[l][r][1] = fma(W.w[7], u1, a0[l][r][1]);
+                    a0[l][r][0] = W.w[6] * u0;
+                    a0[l][r][1] = W.w[6] * u1;
+                }
+            }
+            if (EDGE && l + 1 < K) {
+                // the plane of level l + 1 just completed: k0 - K + p - (l + 1); its cells outside the interior are forced
+                const int z = k0 - K + p - (l + 1);
+                const bool z_in = (unsigned) z < (unsigned) a.h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    d2 hv = {0.0, 0.0};
+                    if ((l + 1) % 2 == 0) hv = *reinterpret_cast<const d2 *>(&delay[(p + 1) % 3][wv][r][2 * lane]);  // written in step p - 2
+                    nv[r][0] = (z_in && in0[r]) ? nv[r][0] : hv.x;
+                    nv[r][1] = (z_in && in1[r]) ? nv[r][1] : hv.y;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v[r][0] = nv[r][0];
+                v[r][1] = nv[r][1];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) outv[r] = (d2){v[r][0], v[r][1]};
+    };
+
+    // Steps whose intermediate planes can lie outside the z range: p < p1 (below plane 0) and p >= p2 (beyond plane h - 1;
+    // two steps early, because the delay line must hold the planes an EDGE step looks back at).  Tiles on the rim in x / y
+    // run the EDGE copy throughout.
+    const int steps = zc + 2 * K + 1;
+    int p1 = min(max(2 * K - k0, 0), steps), p2 = min(max(a.h - k0 + K - 1, p1), steps);
+    if (xy_rim) p1 = steps;
+    int p = 0;
+    for (; p < p1; ++p) step(p, std::true_type{});
+    for (; p < p2; ++p) step(p, std::false_type{});
+    for (; p < steps; ++p) step(p, std::true_type{});
+    // drain: LDS-DMA in flight would land in the LDS of the next workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int TAPSET, int K, int NW>
+hipError_t launch_lanes_t(const Plan &p, const double *in, double *out, int begin, int end, hipStream_t s) {
+    constexpr int OH = 4 * NW - 2 * K;
+    auto kernel = stencil3d_lanes_kernel<TAPSET, K, NW>;
+    static int per_cu[64] = {0};  // resolved once per device (and with it the kernel itself: lora_plan_create's share)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    if (per_cu[dev] == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NW * 64, 0) != hipSuccess || nb < 1) {
+            (void) hipGetLastError();
+            nb = 0;
+        }
+        per_cu[dev] = nb;
+    }
+    if (end <= begin) return hipSuccess;  // prepare_3d_lanes()
+    ArgsL3 a;
+    a.in = in;
+    a.out = out;
+    a.h = p.dims[0];
+    a.m = p.dims[1];
+    a.n = p.dims[2];
+    a.ld = a.n + 8;
+    a.plane = (long) (a.m + 4) * (a.n + 8);
+    if (a.plane * 8 >= (1L << 31)) return hipErrorInvalidValue;  // 32-bit byte offsets inside a plane
+    a.z_begin = begin;
+    a.z_end = end;
+    a.tiles_x = (a.n + kOutW - 1) / kOutW;
+    a.tiles_y = (a.m + OH - 1) / OH;
+    const long tiles = (long) a.tiles_x * a.tiles_y;
+    // z-chunks: ONE round of workgroups when the tiles allow it (a chunk re-reads 2 K planes), else as few rounds as the
+    // depth gives; never chunks shorter than 8 K planes
+    if (p.fused_z_chunk > 0) {
+        a.zc = std::min(p.fused_z_chunk, end - begin);
+    } else {
+        const long slots = (long) std::max(per_cu[dev], 1) * cus;
+        long chunks = std::max(1L, slots / tiles);
+        long zc = (end - begin + chunks - 1) / chunks;
+        zc = std::max(zc, (long) std::min(8 * K, end - begin));
+        a.zc = (int) zc;
+    }
+    const long nblocks = tiles * ((end - begin + a.zc - 1) / a.zc);
+    if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
+    Taps27 w;
+    for (int k = 0; k < 27; ++k) w.w[k] = p.w[k];
+    if (TAPSET == TAPS3D_SEP)
+        for (int k = 0; k < 9; ++k) w.w[k] = p.sep64[k];
+    hipLaunchKernelGGL(kernel, dim3((unsigned) nblocks), dim3(NW * 64), 0, s, a, w);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// K = 4 (or 2) applications in one launch over interior planes [begin, end); star taps or exactly separable box taps
+// (p.sep64_valid), reference boundary
+hipError_t launch_3d_lanes(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s) {
+    if (p.boundary != LORA_BC_REFERENCE || p.dtype != LORA_F64) return hipErrorNotSupported;
+    const bool sep = p.tapset == TAPS3D_BOX && p.sep64_valid;
+    if (p.tapset != TAPS3D_STAR && !sep) return hipErrorNotSupported;
+    if (K == 4) return sep ? launch_lanes_t<TAPS3D_SEP, 4, 8>(p, in, out, begin, end, s) : launch_lanes_t<TAPS3D_STAR, 4, 8>(p, in, out, begin, end, s);
+    if (K == 2) return sep ? launch_lanes_t<TAPS3D_SEP, 2, 8>(p, in, out, begin, end, s) : launch_lanes_t<TAPS3D_STAR, 2, 8>(p, in, out, begin, end, s);
+    return hipErrorInvalidValue;
+}
+
+// one-time host work (kernel resolution, residency query) of the plan's instantiations; no launch
+void prepare_3d_lanes(const Plan &p) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void) hipGetLastError();
+        return;
+    }
+    (void) launch_3d_lanes(p, 4, nullptr, nullptr, 0, 0, nullptr);
+    (void) launch_3d_lanes(p, 2, nullptr, nullptr, 0, 0, nullptr);
+}
+
+const char *kernel_name_3d_lanes(const Plan &) { return "stencil3d_lanes_kernel"; }
+
+}  // namespace lora
