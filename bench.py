@@ -379,6 +379,14 @@ def main():
             if apps != spl:  # 1D: lora_plan_run fuses 16 / 32 sweeps per launch on long runs (the plan's own depth is 8)
                 signature = signature.replace(f"k={spl}", f"k={apps}")
                 spl = apps
+        elif prof.two_launches > 0:
+            # a run too short for a full-depth launch: its shallower fused launches (2D: four / two applications) are the
+            # dominant kernel; their average depth is what the run's sweeps leave after the single sweeps
+            launches = prof.two_launches
+            apps = max((K - prof.single_launches) // prof.two_launches, 1)
+            launch_s = prof.two_ms / 1e3 / prof.two_launches
+            signature = signature.replace(f"k={spl}", f"k={apps}")
+            spl = apps
         else:
             launches, apps, launch_s = max(prof.single_launches, 1), 1, prof.single_ms / 1e3 / max(prof.single_launches, 1)
             single = L.Plan(shape, dims, dtype=args.dtype).set_weights(weights).set_option("steps_per_launch", 1)

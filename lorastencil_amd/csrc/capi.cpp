@@ -353,7 +353,11 @@ void plan_refresh(Plan &p) {
         bool lanes = false;
         if (lanes_taps && p.lanes3 != 0 && p.steps_per_launch_req != 1 && p.steps_per_launch_req != 2 &&
             p.steps_per_launch_req != 3)
-            lanes = p.steps_per_launch_req == 4 || p.lanes3 == 1 || npts >= 6.0e7;
+            // (GStencils/s per launch, plane / tile kernels against this one, tools/lanes3_check.py: star 256^3 508 / 586,
+            // 384^3 531 / 700, 512^3 597 / 795, 768^3 706 / 904; box 256^3 453 / 423, 512^3 581 / 696, 768^3 680 / 818; odd
+            // innermost extent 512 x 512 x 511: 126 (one thread per point) / 782)
+            lanes = p.steps_per_launch_req == 4 || p.lanes3 == 1 ||
+                    npts >= (p.generic ? 1.0e7 : (p.tapset == TAPS3D_STAR ? 1.6e7 : 5.0e7));
         p.lanes3_active = lanes ? 1 : 0;
         if (lanes) {
             p.steps_per_launch = 4;

@@ -299,16 +299,28 @@ hipError_t launch_lanes_t(const Plan &p, const double *in, double *out, int begi
     a.tiles_x = (a.n + kOutW - 1) / kOutW;
     a.tiles_y = (a.m + OH - 1) / OH;
     const long tiles = (long) a.tiles_x * a.tiles_y;
-    // z-chunks: ONE round of workgroups when the tiles allow it (a chunk re-reads 2 K planes), else as few rounds as the
-    // depth gives; never chunks shorter than 8 K planes
+    // z-chunks.  A chunk re-reads 2 K planes and runs 2 K + 1 steps beyond its own, so chunks should be long; but
+    // workgroups on the grid's rim take longer than interior ones, and a single round of long chunks waits for the slowest
+    // (star3d1r 512^3, 110 tiles: chunks of 256 / 171 / 103 / 86 / 64 / 52 / 43 / 32 planes run at 775 / 655 / 728 / 801 /
+    // 810 / 800 / 783 / 691 GStencils/s; box3d1r 768^3, 224 tiles: 256 / 154 / 96 / 64 / 48 / 32: 751 / 767 / 842 / 805 /
+    // 781 / 690 -- gpurun_out/l3_cases.log).  Cost model: whole rounds of workgroups x steps per chunk, with a penalty for
+    // few rounds (nothing evens out the slow workgroups then); chunks of at least 8 K planes.
     if (p.fused_z_chunk > 0) {
         a.zc = std::min(p.fused_z_chunk, end - begin);
     } else {
-        const long slots = (long) std::max(per_cu[dev], 1) * cus;
-        long chunks = std::max(1L, slots / tiles);
-        long zc = (end - begin + chunks - 1) / chunks;
-        zc = std::max(zc, (long) std::min(8 * K, end - begin));
-        a.zc = (int) zc;
+        const long slots = (long) std::max(per_cu[dev], 1) * cus, depth = end - begin;
+        double best = 0.0;
+        long best_c = 1;
+        for (long c = 1; c <= std::max(1L, depth / (8 * K)); ++c) {
+            const long zc = (depth + c - 1) / c, wgs = tiles * ((depth + zc - 1) / zc);
+            const long rounds = (wgs + slots - 1) / slots;
+            const double cost = (double) rounds * (double) (zc + 2 * K + 1) * (1.0 + 0.5 / (double) rounds);
+            if (best == 0.0 || cost < best) {
+                best = cost;
+                best_c = c;
+            }
+        }
+        a.zc = (int) ((depth + best_c - 1) / best_c);
     }
     const long nblocks = tiles * ((end - begin + a.zc - 1) / a.zc);
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;

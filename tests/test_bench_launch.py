@@ -61,10 +61,11 @@ def test_bench_line_roofline_is_a_fraction():
     assert r.returncode == 0, r.stderr[-2000:]
     d = json.loads(lines[-1])
     rf = d["roofline"]
-    assert d["n_gpus"] == 1 and 0 < rf["frac"] <= 1.0 and rf["applications_per_launch"] == 6
+    # 8 sweeps = 6 + 2, which the driver runs as 4 + 4: no full-depth launch, two four-application ones
+    assert d["n_gpus"] == 1 and 0 < rf["frac"] <= 1.0 and rf["applications_per_launch"] == 4
     assert 0 < rf["hbm"]["frac"] <= 1.0 and 0 < rf["fp64"]["frac"] <= 1.0
     assert rf["frac"] == max(rf["hbm"]["frac"], rf["fp64"]["frac"]) and rf["bound"] in ("hbm", "fp64_valu")
-    assert abs(rf["frac_one_sweep_equiv"] - 6 * rf["hbm"]["frac"]) < 1e-3 and rf["launches"] == 1   # 8 sweeps = 6 + 2
-    assert rf["tail_fused_launches"] == 1 and rf["clock_ramp_note"] is not None
+    assert abs(rf["frac_one_sweep_equiv"] - 4 * rf["hbm"]["frac"]) < 1e-3 and rf["launches"] == 2
+    assert rf["tail_fused_launches"] == 2 and rf["clock_ramp_note"] is not None
     assert rf["traffic"] is None or rf["traffic_key"].endswith(rf["kernel"])  # never a number of another kernel
     assert d["cpu_baseline"]["cores"] >= 1

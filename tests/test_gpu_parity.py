@@ -371,7 +371,7 @@ def test_fused_step2_direct_call_and_regions(L, O):
     with pytest.raises(L.LoraError):
         L.Plan("star2d1r", (64, 64)).set_option("steps_per_launch", 8)  # 2D fuses two, four or six applications
     with pytest.raises(L.LoraError):
-        L.Plan("star3d1r", (8, 8, 64)).set_option("steps_per_launch", 4)  # 3D kernels fuse two or three
+        L.Plan("star3d1r", (8, 8, 64)).set_option("steps_per_launch", 8)  # 3D kernels fuse two, three or four (fp64)
     with pytest.raises(L.LoraError):
         L.Plan("1d1r", (64,)).set_option("steps_per_launch", 3)
 
@@ -487,6 +487,67 @@ def test_3d_fused_launches_equal_step_by_step(L, O, shape, dims, cfg):
                 assert np.array_equal(got, exp), f"{shape} {dims} {cfg} t={t} zc={zc}"
             else:
                 assert rel_err(got, exp) < 1e-13, f"{shape} {dims} {cfg} t={t} zc={zc}"
+
+
+@pytest.mark.parametrize("shape", ["star3d1r", "box3d1r"])
+@pytest.mark.parametrize("dims", [(40, 60, 128), (9, 31, 62), (37, 29, 190), (3, 5, 2), (70, 64, 64), (12, 24, 121), (33, 47, 255),
+                                  (30, 100, 260), (1, 1, 1)])
+def test_3d_register_resident_kernel_equals_step_by_step(L, O, shape, dims):
+    """kernels_3d_lanes.hip: FOUR applications per launch with the time levels in registers (x-neighbours by DPP, edge rows
+    through LDS, z streamed), its two-application form for the tails, even and ODD innermost extents, one and many tiles /
+    z-chunks.  Taps arrive in the oracle's order at every level: the whole padded buffer -- interior and the halo state the
+    step-by-step driver leaves behind -- equals the oracle bit for bit while values are exact integers."""
+    a = O.reference_input(shape, dims)
+    plan = L.Plan(shape, dims).set_option("steps_per_launch", 4)
+    assert plan.get_option("steps_per_launch") == 4 and plan.kernel_name == "stencil3d_lanes_kernel"
+    assert L.Plan(shape, dims).set_option("lanes3", 1).kernel_name == "stencil3d_lanes_kernel"
+    assert L.Plan(shape, dims).set_boundary("dirichlet").set_option("lanes3", 1).kernel_name != "stencil3d_lanes_kernel"
+    for t in (4, 5, 6, 7, 8, 9, 12, 13):  # 12, 13: three launches of four, the last two through the scratch grid
+        exp = O.run(shape, a, t)
+        for zc in (0, 3, 9, 40):
+            got = plan_run(L, shape, a, t, options={"steps_per_launch": 4, "fused_z_chunk": zc})
+            if np.abs(exp).max() < 2.0 ** 50:
+                assert np.array_equal(got, exp), f"{shape} {dims} t={t} zc={zc}"
+            else:
+                assert rel_err(got, exp) < 1e-13, f"{shape} {dims} t={t} zc={zc}"
+
+
+@pytest.mark.parametrize("shape", ["star3d1r", "box3d1r"])
+def test_3d_register_resident_kernel_real_data_and_regions(L, O, shape):
+    """Random real data and taps: four applications in one launch == four single sweeps bit for bit (star: same tap order;
+    the separable box to 1e-13: x / y / z passes sum in another order than the 27-tap single sweep) and the oracle to
+    rounding; plane ranges in any order compose (what the slab drivers launch)."""
+    import torch
+
+    rng = np.random.default_rng(23)
+    dims = (45, 70, 250)
+    w = O.effective_weights(shape)
+    if shape == "star3d1r":
+        w = w * rng.uniform(0.5, 1.5, 27)  # any seven star weights
+    w = w / w.sum()
+    a = rng.standard_normal(O.padded_shape(shape, dims))
+    plan = L.Plan(shape, dims).set_weights(w).set_option("steps_per_launch", 4)
+    assert plan.kernel_name == "stencil3d_lanes_kernel"
+    src = torch.from_numpy(a).cuda()
+    dst = torch.from_numpy(a).cuda()
+    dst[1:-1, 2:-2, 4:-4] = -3.0
+    plan.stepk(src, dst)
+    torch.cuda.synchronize()
+    got = dst.cpu().numpy()
+    single = plan_run(L, shape, a, 4, weights=w, options={"steps_per_launch": 1})
+    if shape == "star3d1r":
+        assert np.array_equal(got, single)
+    else:
+        assert rel_err(got, single) < 1e-13
+    assert rel_err(got, O.run(shape, a, 4, weights=w)) < 1e-13
+    dst[1:-1, 2:-2, 4:-4] = -3.0
+    for b, e in ((20, 45), (0, 7), (7, 20)):
+        plan.stepk_region(src, dst, b, e)
+    torch.cuda.synchronize()
+    assert np.array_equal(dst.cpu().numpy(), got)
+    # non-separable 27 taps are not this kernel's: the plan keeps the tile / plane kernels and their two applications
+    p27 = L.Plan("box3d1r", dims).set_weights(rng.random(27)).set_option("steps_per_launch", 4)
+    assert p27.kernel_name != "stencil3d_lanes_kernel" and p27.get_option("steps_per_launch") == 2
 
 
 @pytest.mark.parametrize("shape", ["star3d1r", "box3d1r"])
@@ -1238,7 +1299,7 @@ def test_full_size_constant_field_and_windows(L, O, shape, dims):
     # (4) the fused kernels == single sweeps through buffers whose halo alternates between 0 and the input's, everywhere
     #     (small integers: exact whatever the summation order of the low-rank evaluation)
     k_apps = plan.get_option("steps_per_launch")
-    assert k_apps == (6 if len(dims) == 2 else (3 if shape == "star3d1r" else 2))
+    assert k_apps == (6 if len(dims) == 2 else (4 if shape == "star3d1r" else 2))
     del dst
     two = src.clone()                 # buffer 0 again after two sweeps: the input's halo, new interior
     plan.step(dst2, two)              # dst2 = sweep(src) with a zero halo
@@ -1269,9 +1330,20 @@ def test_full_size_constant_field_and_windows(L, O, shape, dims):
         torch.cuda.synchronize()
         assert torch.equal(fused, four)
         plan.set_option("steps_per_launch", 6)
-    if k_apps == 3:                   # the default 3D star launch: three applications (interior; its halo is the output's)
+    if k_apps == 4 and len(dims) == 3:   # the default launch of a big 3D star grid: four applications, levels in registers
+        assert plan.kernel_name == "stencil3d_lanes_kernel"
         three = torch.zeros_like(src)
         plan.step(two, three)
+        four = src.clone()
+        plan.step(three, four)
+        fused.copy_(src)
+        plan.stepk(src, fused)
+        torch.cuda.synchronize()
+        assert torch.equal(fused, four)
+        del four
+        # and the plane-streaming kernel's three (interior; its halo is the output's), which such grids ran before
+        plan.set_option("steps_per_launch", 3)
+        assert plan.kernel_name == "stencil3d_planes_kernel"
         fused.zero_()
         plan.stepk(src, fused)
         torch.cuda.synchronize()

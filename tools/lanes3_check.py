@@ -74,14 +74,15 @@ def parity():
 
 def timing(out, iters):
     for shape, dims in (("star3d1r", (512, 512, 512)), ("box3d1r", (768, 768, 768)), ("star3d1r", (768, 768, 768)),
-                        ("star3d1r", (256, 256, 256)), ("star3d1r", (384, 384, 384)), ("box3d1r", (512, 512, 512))):
+                        ("star3d1r", (256, 256, 256)), ("star3d1r", (384, 384, 384)), ("box3d1r", (512, 512, 512)), ("star3d1r", (128, 128, 128)),
+                        ("star3d1r", (192, 192, 192)), ("box3d1r", (256, 256, 256)), ("star3d1r", (512, 512, 511))):
         w = L.effective_weights(shape)
         w = w / w.sum()
         ps = L.padded_shape(shape, dims)
         src = torch.rand(ps, dtype=torch.float64, device="cuda")
         dst = torch.zeros(ps, dtype=torch.float64, device="cuda")
         pts = dims[0] * dims[1] * dims[2]
-        for opts in ({"lanes3": 0}, {"steps_per_launch": 4}, {"steps_per_launch": 4, "fused_z_chunk": 128}, {"steps_per_launch": 4, "fused_z_chunk": 64}):
+        for opts in ({"lanes3": 0}, {"steps_per_launch": 4}, {"steps_per_launch": 4, "fused_z_chunk": 48}, {"steps_per_launch": 4, "fused_z_chunk": 96}):
             plan = L.Plan(shape, dims).set_weights(w)
             for k, v in opts.items():
                 plan.set_option(k, v)
