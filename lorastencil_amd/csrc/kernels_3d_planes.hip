@@ -91,14 +91,21 @@ __device__ __forceinline__ d2 load_halo_pair(const double *p) {
     return v;
 }
 
-// The same in two halves, for several loads behind one wait: the loads write registers the compiler believes ready,
-// so the wait takes them as in/out operands -- every use comes after it, and the registers stay reserved in between.
-__device__ __forceinline__ void issue_halo_pair(d2 &v, const double *p) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(v) : "v"(p) : "memory");
-}
-
-__device__ __forceinline__ void wait_halo_pairs(d2 &a, d2 &b, d2 &c, d2 &d) {
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+// Four of them behind ONE wait, in ONE statement: the loads' destination registers are outputs of the statement that also
+// waits for them, so the compiler never sees a register whose load is still in flight (issued and waited for in two
+// statements, it may copy, re-materialise or spill such a register in between and keep the stale value -- the register-
+// resident 3D kernel's first version computed wrong planes that way at 256 VGPRs).  Every lane loads; lanes that need
+// nothing pass a harmless address and ignore the result.
+__device__ __forceinline__ void load_halo_pairs4(d2 (&v)[4], const double *p0, const double *p1, const double *p2, const double *p3) {
+    asm volatile(
+        "global_load_dwordx4 %0, %4, off\n\t"
+        "global_load_dwordx4 %1, %5, off\n\t"
+        "global_load_dwordx4 %2, %6, off\n\t"
+        "global_load_dwordx4 %3, %7, off\n\t"
+        "s_waitcnt vmcnt(0)"
+        : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+        : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+        : "memory");
 }
 
 template <int N>
@@ -338,6 +345,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_planes_kernel(const Args
                 // slowest (rim) workgroups set the launch time
                 d2 hv[kRY];
                 bool need[kRY];
+                const double *hp[kRY];
 #pragma unroll
                 for (int r = 0; r < kRY; ++r) {
                     const bool in = zc_in && row + r >= 0 && row + r < a.m;
@@ -345,10 +353,17 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_planes_kernel(const Args
                     // cells beyond the padded array feed no valid output
                     need[r] = !in && lvl_halo[L] && pz >= 0 && pz <= a.h + 1 && pr >= 0 && pr <= a.m + 3 && pc >= 0 &&
                               pc + 1 <= a.n + 7;
-                    hv[r] = (d2){0.0, 0.0};
-                    if (need[r]) issue_halo_pair(hv[r], a.halo_src + (long) pz * a.plane + (long) pr * a.ld + pc);
+                    hp[r] = need[r] ? a.halo_src + (long) pz * a.plane + (long) pr * a.ld + pc : a.halo_src;
                 }
-                if (lvl_halo[L]) wait_halo_pairs(hv[0], hv[1], hv[2], hv[3]);
+                static_assert(kRY == 4, "four halo loads per level");
+                if (lvl_halo[L]) {
+                    load_halo_pairs4(hv, hp[0], hp[1], hp[2], hp[3]);
+#pragma unroll
+                    for (int r = 0; r < kRY; ++r) hv[r] = need[r] ? hv[r] : (d2){0.0, 0.0};
+                } else {
+#pragma unroll
+                    for (int r = 0; r < kRY; ++r) hv[r] = (d2){0.0, 0.0};
+                }
 #pragma unroll
                 for (int r = 0; r < kRY; ++r) {
                     const bool in = zc_in && row + r >= 0 && row + r < a.m;
