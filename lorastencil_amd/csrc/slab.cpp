@@ -539,12 +539,16 @@ int lora_slab_create(lora_slab **out, const lora_slab_desc *d, const lora_slab_c
         (void) lora_plan_get_option(probe, "steps_per_launch", &apps);
         lora_plan_destroy(probe);
         if (d->flags & LORA_SLAB_NO_FUSION) apps = 1;
-        if (nd == 3 && apps > 2) apps = 2;  // slab launches start at even steps on buffers that both carry the halo
-        // 2D: the single-GPU driver fuses six sweeps per launch (kernels_2d_wg.hip: one round of long chunks); a slab is a
-        // fraction of the grid's rows, where the 41 recomputed rows of each of its chunks weigh more: slab launches keep
-        // four per launch (row-streaming kernel) unless the options ask for six
-        if (nd == 2 && apps == 6 && !(d->options && std::strstr(d->options, "steps_per_launch="))) apps = 4;
-        while (apps > 1 && splitting && thinnest < s->radius * apps) apps = (nd == 2 && apps >= 4) ? apps - 2 : 1;
+        // slab launches start at even steps on buffers that both carry the halo: an even number of applications -- four
+        // (register-resident kernel, big fp64 grids) or two; the three of the single-GPU plane-streaming schedule become two
+        if (nd == 3 && apps == 3) apps = 2;
+        // (2D slabs keep the plan's six per launch: ring-of-one shares of star2d1r 16384^2 at 8 GPUs, GStencils/s per rank,
+        // six (workgroup-row kernel) / four (the same) / four (row-streaming): 847 / 825 / 703 -- tools/slab_shares.py)
+        // 3D: the register-resident kernel wants z-chunks of 32 planes and more; on slabs thinner than ~96 planes the
+        // two-application kernels are faster (star3d1r 512^3 shares, four / two per launch: 128 planes 489 / 431, 64 planes
+        // 253 / 321)
+        if (nd == 3 && apps == 4 && splitting && thinnest < 96 && !(d->options && std::strstr(d->options, "steps_per_launch="))) apps = 2;
+        while (apps > 1 && splitting && thinnest < s->radius * apps) apps = (nd >= 2 && apps >= 4) ? apps - 2 : 1;
     }
     s->apps = apps;
     s->fused = apps > 1;
@@ -694,7 +698,7 @@ int lora_slab_run_many(lora_slab **ss, int n, int times) {
         int napps = 1;
         if (s0->fused && even && times - t >= s0->apps)
             napps = s0->apps;
-        else if (s0->fused && even && s0->nd == 2 && s0->apps >= 4 && times - t >= 2)
+        else if (s0->fused && even && s0->nd >= 2 && s0->apps >= 4 && times - t >= 2)
             napps = 2;
         if (int rc = launch_all(ss, n, napps)) return rc;
         t += napps;

@@ -146,17 +146,18 @@ class HipStepper:
             self.plan.set_option(k, int(v))
         if boundary == "dirichlet":
             self.plan.set_boundary(boundary)  # fused launches: intermediate halo cells keep the source's values
-        if (len(layout.local_dims) == 2 and self.plan.get_option("steps_per_launch") == 6
-                and "steps_per_launch" not in (options or {})):
-            # the single-GPU driver fuses six sweeps per launch (kernels_2d_wg.hip: one round of long chunks); a slab is a
-            # fraction of the grid's rows, where the 41 recomputed rows of each of its chunks weigh more: slab launches
-            # keep four per launch (row-streaming kernel) unless asked otherwise
-            self.plan.set_option("steps_per_launch", 4)
+        if (len(layout.local_dims) == 3 and self.plan.get_option("steps_per_launch") == 4 and layout.ghost > 0
+                and layout.own < 96 and "steps_per_launch" not in (options or {})):
+            # the register-resident 3D kernel wants z-chunks of 32 planes and more: on slabs thinner than ~96 planes the
+            # two-application kernels are faster (ring-of-one shares of star3d1r 512^3, GStencils/s per rank, four / two per
+            # launch: 128 planes 489 / 431, 64 planes 253 / 321; tools/slab_shares.py)
+            self.plan.set_option("steps_per_launch", 2)
         if boundary == "periodic":
             self.plan.set_option("steps_per_launch", 1)  # a fused launch would need the wrap of its inner levels
-        elif len(layout.local_dims) == 3 and self.plan.get_option("steps_per_launch") > 2:
-            # the single-GPU driver fuses three sweeps per launch on the reference's alternating buffer state; slab
-            # launches start at even steps on buffers that both carry the halo: two per launch
+        elif len(layout.local_dims) == 3 and self.plan.get_option("steps_per_launch") == 3:
+            # the single-GPU plane-streaming schedule fuses three sweeps per launch on the reference's alternating buffer
+            # state; slab launches start at even steps on buffers that both carry the halo: two per launch (or the four of
+            # the register-resident kernel, which the plan resolves by itself on big fp64 grids)
             self.plan.set_option("steps_per_launch", 2)
         # launches go to the stream that is current when the driver is built (looked up once: at 8 GPUs a launch is
         # ~100 us of GPU time, so per-call host work matters)
@@ -237,7 +238,7 @@ class SlabDriver:
         # applications of a fused launch (lora_plan_stepk): 8 in 1D, 4 (row-streaming kernel) or 2 in 2D, 2 in 3D -- the
         # first candidate the stepper agrees with decides the ghost depth
         default_apps = 8 if nd == 1 else 2
-        candidates = {1: [8], 2: [6, 4, 2], 3: [2]}[nd]
+        candidates = {1: [8], 2: [6, 4, 2], 3: [4, 2]}[nd]
         for apps in (candidates + [1] if fused else [1]):
             need = radius * apps
             split = self.world_size > 1 or self._ring
@@ -524,7 +525,7 @@ class SlabDriver:
                 if self.fused and even and times - t >= self.apps:
                     self._launch(self.apps)
                     t += self.apps
-                elif (self.fused and even and self.ndim == 2 and self.apps >= 4 and times - t >= 2
+                elif (self.fused and even and self.ndim >= 2 and self.apps >= 4 and times - t >= 2
                       and hasattr(self.stepper, "step2_region")):
                     self._launch(2)
                     t += 2

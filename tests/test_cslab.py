@@ -49,32 +49,36 @@ def test_slab_descriptor_validation(L):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape,dims,nranks,times,every,flags", [
-    ("star2d1r", (384, 256), 3, 11, 0, 0),     # four applications per launch: 4 + 4 + 2 + 1
-    ("star2d1r", (768, 384), 2, 23, 2, 0),     # 24-row ghost zones refreshed every 2 launches, deferred waits
-    ("star2d1r", (768, 384), 4, 16, 1, 1),     # no boundary-first overlap
-    ("star2d1r", (768, 384), 4, 16, 2, 2),     # no deferred wait
-    ("box2d3r", (300, 130), 3, 6, 3, 0),
-    ("star2d3r", (256, 200), 2, 9, 1, 4),      # single sweeps only
-    ("star3d1r", (24, 20, 64), 3, 7, 2, 0),
-    ("box3d1r", (30, 16, 64), 2, 8, 0, 0),
-    ("1d1r", (30000,), 3, 27, 2, 0),           # eight applications per launch + single sweeps
+@pytest.mark.parametrize("shape,dims,nranks,times,every,flags,opts", [
+    ("star2d1r", (384, 256), 3, 11, 0, 0, {"steps_per_launch": 4}),     # four applications per launch: 4 + 4 + 2 + 1
+    ("star2d1r", (768, 384), 2, 23, 2, 0, {"steps_per_launch": 4}),     # 24-row ghost zones refreshed every 2 launches, deferred waits
+    ("star2d1r", (768, 384), 4, 16, 1, 1, None),     # six per launch (the default: workgroup-row kernel); no boundary-first overlap
+    ("star2d1r", (768, 384), 4, 16, 2, 2, None),     # no deferred wait
+    ("star2d1r", (768, 384), 3, 21, 1, 0, None),     # 6 + 6 + 6 + 2 + 1
+    ("box2d3r", (300, 130), 3, 6, 3, 0, None),
+    ("star2d3r", (256, 200), 2, 9, 1, 4, None),      # single sweeps only
+    ("star3d1r", (24, 20, 64), 3, 7, 2, 0, None),
+    ("box3d1r", (30, 16, 64), 2, 8, 0, 0, None),
+    ("star3d1r", (60, 40, 130), 3, 11, 1, 0, {"steps_per_launch": 4}),  # the register-resident kernel in z-slabs: 4 + 4 + 2 + 1
+    ("box3d1r", (64, 30, 250), 4, 14, 2, 0, {"steps_per_launch": 4}),
+    ("1d1r", (30000,), 3, 27, 2, 0, None),           # eight applications per launch + single sweeps
 ])
-def test_loopback_slabs_equal_single_gpu(L, shape, dims, nranks, times, every, flags):
+def test_loopback_slabs_equal_single_gpu(L, shape, dims, nranks, times, every, flags, opts):
     from lorastencil_amd import cslab
     from oracle import oracle as O
 
     a = O.reference_input(shape, dims)
     # one slab, same launch schedule (the run is split in two calls below): N slabs must equal it BIT FOR BIT -- same
     # kernels, same per-point arithmetic whatever the decomposition -- even where values have left the exact range
-    one = cslab.SlabSet(shape, dims, 1, flags=flags & 4)
+    one = cslab.SlabSet(shape, dims, 1, flags=flags & 4, options=opts)
     one.load(a)
     one.run(times // 2)
     one.run(times - times // 2)
     single = one.store(np.zeros_like(a))
-    slabs = cslab.SlabSet(shape, dims, nranks, comms=cslab.loopback_comms(nranks), exchange_every=every, flags=flags)
+    slabs = cslab.SlabSet(shape, dims, nranks, comms=cslab.loopback_comms(nranks), exchange_every=every, flags=flags,
+                          options=opts)
     si = slabs.info(0)
-    assert si.apps_per_launch == (1 if flags & 4 else {1: 8, 2: 4, 3: 2}[len(dims)])
+    assert si.apps_per_launch == (1 if flags & 4 else (opts or {}).get("steps_per_launch", {1: 8, 2: 6, 3: 2}[len(dims)]))
     assert si.ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * si.apps_per_launch * si.exchange_every
     slabs.load(a)
     slabs.run(times // 2)          # resumable at any time level
@@ -175,5 +179,5 @@ def test_cli_gpus_flag_over_loopback(L):
     finally:
         del os.environ["LORA_SLAB_LOOPBACK"]
     exp = O.run("star2d1r", a, 9)  # 100^9 has left the exact-integer range: compared to rounding
-    assert np.abs(out - exp).max() <= 1e-13 * np.abs(exp).max() and info.steps_per_launch == 4
+    assert np.abs(out - exp).max() <= 1e-13 * np.abs(exp).max() and info.steps_per_launch == 6
     assert np.array_equal(out[:4], exp[:4]) and np.array_equal(out[:, :4], exp[:, :4])  # halo state after an odd run: 0

@@ -1582,8 +1582,8 @@ def _slab_rank(rank, world, port, shape, dims, times, every, dtype, q, boundary=
 
 
 @pytest.mark.parametrize("shape,dims,times,every,dtype", [
-    ("star2d1r", (384, 256), 9, 2, "f64"),     # fused pairs + odd tail, 12-row ghost zones
-    ("star2d1r", (768, 384), 16, 4, "f64"),    # the bench configuration: 24-row ghost zones, refresh every 4 launches
+    ("star2d1r", (384, 256), 9, 2, "f64"),     # a six-application launch + 2 + 1, 36-row ghost zones
+    ("star2d1r", (768, 384), 16, 4, "f64"),    # 72-row ghost zones, refresh every 4 launches
     ("box2d3r", (300, 130), 6, 3, "f64"),
     ("star3d1r", (24, 20, 64), 7, 2, "f64"),
     ("box3d1r", (24, 20, 64), 6, 3, "bf16"),
@@ -1620,8 +1620,8 @@ def test_three_rank_slabs_on_one_gpu_equal_single_rank(L, O, shape, dims, times,
             assert np.array_equal(got, exp)
         else:
             assert rel_err(got, exp) < 1e-13
-    assert fused  # 1D: eight applications per launch, 2D: four (row-streaming kernel), 3D fp64 and bf16: two
-    assert ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * {1: 8, 2: 4, 3: 2}[len(dims)] * every
+    assert fused  # 1D: eight applications per launch, 2D: six (workgroup-row kernel), 3D fp64 (small grids) and bf16: two
+    assert ghost == {1: 4, 2: 3, 3: 1}[len(dims)] * {1: 8, 2: 6, 3: 2}[len(dims)] * every
 
 
 @pytest.mark.parametrize("boundary", ["dirichlet", "periodic"])
@@ -1689,7 +1689,7 @@ for shape, dims, steps in (("star2d1r", (256, 384), 7), ("star3d1r", (24, 20, 64
         if not same:
             print("RING_MISMATCH", shape, mode)
         ok = ok and same
-# the deferred wait over a STREAM-ORDERED backend: non-periodic, fused (four applications per launch), ghost zones
+# the deferred wait over a STREAM-ORDERED backend: non-periodic, fused (six applications per launch), ghost zones
 # refreshed every 2 launches, so a launch sweeps its deep interior, waits for the ghost rows in flight, then sweeps its
 # rims.  (A ring of one under the reference boundary is a rehearsal of one rank's share, not a physical result: what
 # must hold is that the overlapped / deferred schedule equals the plain one bit for bit.)  The driver is built while a
@@ -1702,7 +1702,7 @@ for defer, overlap in (("1", True), ("0", False)):
     side = torch.cuda.Stream()
     with torch.cuda.stream(side):
         drv = slab.SlabDriver("star2d1r", (512, 384), device="cuda:0", ring_of_one=True, exchange_every=2, overlap=overlap)
-    assert drv.fused and drv.apps == 4 and drv.layout.ghost == 24 and drv.defer_wait == (defer == "1")
+    assert drv.fused and drv.apps == 6 and drv.layout.ghost == 36 and drv.defer_wait == (defer == "1")
     drv.load_global(a); drv.refresh_ghosts(); drv.run(23)
     side.synchronize(); torch.cuda.synchronize()
     res.append(drv.result().cpu().numpy().copy())
