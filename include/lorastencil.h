@@ -175,7 +175,7 @@ int lora_set_default_normalize(int on);
  *   steps_per_launch  0 auto / 1 / 2 (2D also 4 with the row-streaming kernel and 6 with the workgroup-row kernel, 3D fp64
  *                     also 3 with the plane-streaming kernel, 1D also 4, 8, 16, 32) : applications per launch in
  *                     lora_plan_run (temporal fusion).  2D auto: 6 (reference boundary; what six leave of a run is covered by
- *                     one launch of four and / or two); 4 for plain 49-tap tables; 2 under the Dirichlet option.  1D auto:
+ *                     one launch of four and / or two); 4 for plain 49-tap tables and under the Dirichlet option.  1D auto:
  *                     the plan's own depth is 8 (lora_plan_stepk, slabs); lora_plan_run uses 16 from 32 sweeps on and
  *                     32 from 64 on
  *   rows_per_thread, panel_width, nt_store, fused_rows, persistent      2D tile shape / block->tile map / stores

@@ -274,6 +274,13 @@ void plan_refresh(Plan &p) {
         p.wg_active = p.stream2 && p.boundary == LORA_BC_REFERENCE && p.variant == LORA_VARIANT_DIRECT &&
                       (p.steps_per_launch == 6 || (p.wg == 1 && p.steps_per_launch >= 2)) && p.wg != 0;
         if (p.steps_per_launch == 6 && !p.wg_active) p.steps_per_launch = 4;
+        // The Dirichlet option: the workgroup-row kernel at FOUR applications per launch (a row of halo values per level;
+        // six would need 98 KB of LDS per workgroup), unless the plan asks for two or switches the kernel off
+        if (p.boundary == LORA_BC_DIRICHLET && !p.generic && p.stream2 && p.wg != 0 && p.variant == LORA_VARIANT_DIRECT &&
+            p.fused_eval != TAPS2D_BOX && (p.steps_per_launch_req == 0 || p.steps_per_launch_req >= 4)) {
+            p.steps_per_launch = 4;
+            p.wg_active = 1;
+        }
         if (p.wg_active) prepare_2d_wg(p);  // kernel resolution + residency query now, not in the first launch of a run
         p.kernel_name = (p.generic && p.steps_per_launch == 1) ? kernel_name_generic(p)
                         : (p.variant == LORA_VARIANT_MFMA)
@@ -1057,6 +1064,9 @@ static FusedSchedule fused_schedule(lora_plan *plan, int times, bool can_fuse, b
             fs.tail[0] = K == 6 ? 4 : 2;
             fs.tail[1] = 2;
             fs.n2 += 2;
+        } else if (fs.n2 > 0 && fs.tail[fs.n2 - 1] >= 4) {
+            fs.tail[fs.n2 - 1] = 2;  // a four-application launch as two of two
+            fs.tail[fs.n2++] = 2;
         } else if (fs.n2 > 0) {
             fs.n2 -= 1;
         } else {

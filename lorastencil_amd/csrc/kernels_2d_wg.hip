@@ -36,6 +36,7 @@
 //     the store just issued (last stage), every step (measured: rim workgroups 2.3 x slower).  Instead stage 0 fetches
 //     them one step ahead, global -> LDS like the rows, into a row of halo values per even level (range-checked offsets:
 //     lanes that need nothing make no memory request), where every stage picks them up behind the step's barrier.
+//     Under the Dirichlet option every level keeps the source's values: a row of halo values per level (K = 4 and 2).
 // Per accumulator the taps arrive in the same order as in the other fused 2D kernels: results are bit-identical to them.
 //
 // Replaces the reference's time-step loop 2d/gpu.cu:544-546 (K steps per pass) and kernels 2d/gpu.cu:31-273.
@@ -76,17 +77,19 @@ constexpr int kBufW = 520;  // doubles of a level row buffer: the last lanes' wi
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 // ring of input rows | two copies of a row per intermediate level | two copies of a row of halo values per even level
-__host__ __device__ constexpr int wg_lds_doubles(int K, int D) { return (D + 1) * kRowW + (K - 1) * 2 * kBufW + (K / 2 - 1) * 2 * kRowW + 8; }
+// (DIRI: the Dirichlet option -- every intermediate level keeps the source's halo values, not only the even ones)
+__host__ __device__ constexpr int wg_halo_levels(int K, bool DIRI) { return DIRI ? K - 1 : K / 2 - 1; }
+__host__ __device__ constexpr int wg_lds_doubles(int K, int D, bool DIRI) { return (D + 1) * kRowW + (K - 1) * 2 * kBufW + wg_halo_levels(K, DIRI) * 2 * kRowW + 8; }
 
 // Step r of a chunk whose first output row is i0: stage 0 consumes input row i0 - 3 K + r; level l completes its row
 // i0 - 3 K - 4 l + 1 + r (a level lags 3 rows -- its radius -- plus one step of hand-off behind the level below).
 // Level K is the output.  Ring slot of input row r: r mod (D + 1); row buffer of level l written in step r: copy r mod 2.
-template <int EVAL, int KL, int S, int D, int WPS>
+template <int EVAL, int KL, int S, int D, int WPS, bool DIRI>
 __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG a, const Taps49 W, const LowRankTaps F) {
     constexpr int K = KL * S, NS = D + 1;
     static_assert(NS == 4 || NS == 2, "ring slots: a power of two");
     static_assert(K % 2 == 0, "fused launches move an even number of levels");
-    __shared__ __attribute__((aligned(128))) double lds[wg_lds_doubles(K, D)];
+    __shared__ __attribute__((aligned(128))) double lds[wg_lds_doubles(K, D, DIRI)];
     double *const ring = lds;
     double *const rb = lds + NS * kRowW;  // rb + ((l - 1) * 2 + copy) * kBufW: row of level l
 
@@ -175,12 +178,12 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
         // Stage 0, EDGE: per even level 2 e + 2 (of ANY stage) the byte offset of this lane's cell in a padded row when the
         // lane needs the source's value there (0x80000000 = beyond the descriptor's range: no memory request) --
         // `hcol` in rows of the interior (rim columns only), `hall` in rows outside it (every lane)
-        constexpr int NH = K / 2 - 1;
+        constexpr int NH = wg_halo_levels(K, DIRI);  // levels with halo values: level DIRI ? e + 1 : 2 e + 2 is number e
         unsigned hcol[NH > 0 ? NH : 1], hall[NH > 0 ? NH : 1];
         if (FIRST) {
 #pragma unroll
             for (int e = 0; e < NH; ++e) {
-                const int c0 = j0 - 3 * K + 3 * (2 * e + 2) + 2 * t;
+                const int c0 = j0 - 3 * K + 3 * (DIRI ? e + 1 : 2 * e + 2) + 2 * t;
                 hall[e] = 8u * (unsigned) min(max(c0 + 4, 0), a.n + 6);
                 hcol[e] = ((unsigned) c0 < (unsigned) a.n && (unsigned) (c0 + 1) < (unsigned) a.n) ? 0x80000000u : hall[e];
             }
@@ -218,8 +221,8 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
                 }
                 // EDGE: what this lane's cells are forced to when they lie outside the interior
                 d2 h = {0.0, 0.0};
-                if (EDGE && !to_global && (l & 1) == 0)
-                    h = *reinterpret_cast<const d2 *>(winp + NS * kRowW + (K - 1) * 2 * kBufW + ((l / 2 - 1) * 2 + par) * kRowW);
+                if (EDGE && !to_global && ((l & 1) == 0 || DIRI))
+                    h = *reinterpret_cast<const d2 *>(winp + NS * kRowW + (K - 1) * 2 * kBufW + ((DIRI ? l - 1 : l / 2 - 1) * 2 + par) * kRowW);
                 // the newest logical row (6) starts from zero: stated here, so that the zero is an inline constant of its
                 // first multiply-add and not a register carried around the loop
                 pa[j][(P + 6) % 7] = 0.0;
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
                     // halo values of step r + 1, every even level: this wave's 128 columns of them
 #pragma unroll
                     for (int e = 0; e < NH; ++e) {
-                        const int row1 = i0 - 3 * K - 4 * (2 * e + 2) + 1 + (r + 1);
+                        const int row1 = i0 - 3 * K - 4 * (DIRI ? e + 1 : 2 * e + 2) + 1 + (r + 1);
                         const int pr = min(max(row1 + 4, 0), a.m + 7);
                         const __amdgpu_buffer_rsrc_t hsrc = __builtin_amdgcn_make_buffer_rsrc(
                             const_cast<double *>(a.in) + (size_t) pr * a.ld, 0, (unsigned) a.ld * 8u, 0x00020000);
@@ -344,13 +347,13 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
 // Workgroups of this instantiation that are resident per CU (cached per device).  The first query of an instantiation
 // also makes the runtime load and resolve the kernel -- half a millisecond of host time that lora_plan_create /
 // lora_plan_set_* pay through prepare_2d_wg(), not the first launch of a run.
-template <int EVAL, int KL, int S, int D, int WPS>
+template <int EVAL, int KL, int S, int D, int WPS, bool DIRI>
 int wg_per_cu(int dev) {
     static int per_cu[64] = {0};
     if (dev < 0 || dev >= 64) dev = 0;
     if (per_cu[dev] == 0) {
         int nb = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stencil2d_wg_kernel<EVAL, KL, S, D, WPS>, 256 * S, 0) != hipSuccess || nb < 1) {
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stencil2d_wg_kernel<EVAL, KL, S, D, WPS, DIRI>, 256 * S, 0) != hipSuccess || nb < 1) {
             (void) hipGetLastError();
             return 1;  // (no device: asked again later)
         }
@@ -359,10 +362,10 @@ int wg_per_cu(int dev) {
     return per_cu[dev];
 }
 
-template <int EVAL, int KL, int S, int D, int WPS>
+template <int EVAL, int KL, int S, int D, int WPS, bool DIRI>
 hipError_t launch_wg_t(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
     constexpr int K = KL * S;
-    auto kernel = stencil2d_wg_kernel<EVAL, KL, S, D, WPS>;
+    auto kernel = stencil2d_wg_kernel<EVAL, KL, S, D, WPS, DIRI>;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     {
@@ -370,7 +373,7 @@ hipError_t launch_wg_t(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
     }
     // one round: as many workgroups as are resident at once
-    const int per_cu_dev = wg_per_cu<EVAL, KL, S, D, WPS>(dev);
+    const int per_cu_dev = wg_per_cu<EVAL, KL, S, D, WPS, DIRI>(dev);
     if (rows_total <= 0) return hipSuccess;  // prepare_2d_wg(): the query above is all that was wanted
     const int lag = 7 * K - 1;  // steps of a chunk beyond its output rows
     auto fit = [&](long rows) {
@@ -436,7 +439,10 @@ hipError_t launch_wg_t(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
 #endif
 template <int EVAL>
 hipError_t launch_wg_e(const Plan &p, const ArgsWG &a, int rows_total, hipStream_t s) {
-    return launch_wg_t<EVAL, LORA_WG_K / 2, 2, 3, 4>(p, a, rows_total, s);
+#if LORA_WG_K <= 4  // the Dirichlet option: halo values at every level (K = 6 would need 98 KB of LDS per workgroup)
+    if (p.boundary == LORA_BC_DIRICHLET) return launch_wg_t<EVAL, LORA_WG_K / 2, 2, 3, 4, true>(p, a, rows_total, s);
+#endif
+    return launch_wg_t<EVAL, LORA_WG_K / 2, 2, 3, 4, false>(p, a, rows_total, s);
 }
 
 }  // namespace
@@ -501,7 +507,7 @@ long long *g_wg_stamps = nullptr;  // set by the probe: 4 x int64 per workgroup
 hipError_t launch_2d_wg(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s) {
     if (end <= begin) return hipSuccess;
     if (K != 6 && K != 4 && K != 2) return hipErrorInvalidValue;
-    if (p.boundary != LORA_BC_REFERENCE) return hipErrorNotSupported;  // (halo values exist for the even levels only)
+    if (p.boundary == LORA_BC_PERIODIC || (p.boundary == LORA_BC_DIRICHLET && K == 6)) return hipErrorNotSupported;
     ArgsWG a;
     a.in = in;
     a.out = out;

@@ -349,7 +349,9 @@ def test_fused_step2_direct_call_and_regions(L, O):
     assert L.Plan(shape, dims).kernel_name == "stencil2d_wg_kernel"
     assert L.Plan(shape, dims).get_option("steps_per_launch") == 6
     assert L.Plan(shape, dims).set_option("steps_per_launch", 4).kernel_name == "stencil2d_stream_kernel"
-    assert L.Plan(shape, dims).set_boundary("dirichlet").get_option("steps_per_launch") == 2  # six / four: reference BC only
+    pd = L.Plan(shape, dims).set_boundary("dirichlet")  # four per launch: the workgroup-row kernel with halo values at every level
+    assert pd.get_option("steps_per_launch") == 4 and pd.kernel_name == "stencil2d_wg_kernel"
+    assert L.Plan(shape, dims).set_boundary("dirichlet").set_option("wg", 0).get_option("steps_per_launch") == 2
     assert L.Plan(shape, dims).set_option("stream", 0).get_option("steps_per_launch") == 2
     _check_step2_and_regions(L, O, shape, dims, a, exp, {"stream": 0}, "stencil2d_fused2_kernel")
     _check_step2_and_regions(L, O, shape, dims, a, exp, {}, "stencil2d_stream_kernel")
@@ -1076,13 +1078,14 @@ def test_graph_replay_of_launch_bound_runs(L, O, shape, dims, t):
 @pytest.mark.parametrize("shape,dims", [("star2d1r", (64, 128)), ("star2d1r", (53, 246)), ("box2d3r", (40, 130)),
                                         ("star2d3r", (200, 380)), ("star3d1r", (9, 20, 136)), ("box3d1r", (6, 5, 8)),
                                         ("1d1r", (4096,)), ("star2d1r", (33, 65)), ("star3d1r", (40, 70, 200)),
-                                        ("box3d1r", (33, 35, 130))])
+                                        ("box3d1r", (33, 35, 130)), ("star2d1r", (300, 1000)), ("box2d3r", (90, 1430)),
+                                        ("star2d3r", (13, 952))])
 def test_boundary_condition_options(L, O, shape, dims, bc):
     """fixed (Dirichlet) and periodic halos as driver options, against the oracle's restatement."""
     import torch
 
     a = O.reference_input(shape, dims)
-    for t in (1, 4, 5, 8):
+    for t in (1, 4, 5, 8, 9, 14):  # 2D Dirichlet: launches of four (workgroup-row kernel), tails of two, single sweeps
         plan = L.Plan(shape, dims).set_boundary(bc)
         b0 = torch.from_numpy(a).cuda()
         b1 = torch.zeros_like(b0)
