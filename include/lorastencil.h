@@ -249,6 +249,10 @@ int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int b
  * the boundary options and the fused launches' halo bookkeeping; exported for drivers that step themselves. */
 enum lora_halo_mode { LORA_HALO_COPY = 0, LORA_HALO_ZERO = 1, LORA_HALO_WRAP = 2 };
 int lora_plan_halo(lora_plan *plan, void *d_dst, const void *d_src, int mode, void *stream);
+/* rows x cols fp64 elements from one strided device array to another (leading dimensions in elements): the pack / unpack
+ * kernel of a 2-D block decomposition's COLUMN ghost zones (lorastencil_amd/blocks.py) -- a slab's ghost rows
+ * are contiguous and need none.  Asynchronous on `stream`. */
+int lora_copy_block_f64(void *d_dst, long dst_ld, const void *d_src, long src_ld, long rows, long cols, void *stream);
 /* The time-step driver (2d/gpu.cu:544-546): `times` applications ping-ponging between the two
  * buffers starting from d_buf0; the result is in buffer [times % 2] (the other buffer's interior is
  * unspecified).  The caller must have put the padded input in d_buf0 and zeros in d_buf1 to get the

@@ -154,6 +154,7 @@ SIGNATURES = {
     "lora_plan_region_granularity": (ctypes.c_int, [_vp]),
     "lora_plan_step2": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "lora_plan_halo": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),
+    "lora_copy_block_f64": (ctypes.c_int, [_vp, ctypes.c_long, _vp, ctypes.c_long, ctypes.c_long, ctypes.c_long, _vp]),
     "lora_plan_stepk": (ctypes.c_int, [_vp, _vp, _vp, _vp]),
     "lora_plan_step2_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lora_plan_stepk_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),

@@ -908,6 +908,18 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
     return LORA_OK;
 }
 
+int lora_copy_block_f64(void *d_dst, long dst_ld, const void *d_src, long src_ld, long rows, long cols, void *stream) {
+    if (!d_dst || !d_src || rows < 0 || cols < 0 || dst_ld < cols || src_ld < cols) return LORA_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(d_dst) | reinterpret_cast<uintptr_t>(d_src)) & 7) return LORA_EUNSUPPORTED;
+    const hipError_t e = lora::launch_copy_block(static_cast<double *>(d_dst), dst_ld, static_cast<const double *>(d_src), src_ld,
+                                                 rows, cols, static_cast<hipStream_t>(stream));
+    if (e != hipSuccess) {
+        lora::set_last_error("block copy kernel launch", e);
+        return LORA_EHIP;
+    }
+    return LORA_OK;
+}
+
 int lora_plan_halo(lora_plan *plan, void *d_dst, const void *d_src, int mode, void *stream) {
     if (!plan || !d_dst) return LORA_EINVAL;
     if (mode != LORA_HALO_COPY && mode != LORA_HALO_ZERO && mode != LORA_HALO_WRAP) return LORA_EINVAL;

@@ -123,6 +123,8 @@ hipError_t launch_2d_fused2(const Plan &p, const double *in, double *out, int be
 // halo cells of a padded array (any shape / element type): copy from src, zero, or periodic wrap from dst itself
 enum HaloMode { HALO_COPY = 0, HALO_ZERO = 1, HALO_WRAP = 2 };
 hipError_t launch_halo(const Plan &p, void *dst, const void *src, int mode, hipStream_t s);
+// rows x cols doubles between two strided arrays (pack / unpack of a block decomposition's column ghost zones)
+hipError_t launch_copy_block(double *dst, long dst_ld, const double *src, long src_ld, long rows, long cols, hipStream_t s);
 const char *kernel_name_2d_fused2(const Plan &p);
 // the same two applications per launch, row-streaming form (wave-autonomous column strips)
 // (K = 2 or 4 applications per launch)

@@ -9,9 +9,13 @@
 // Halo widths follow the reference layouts: 4 (1D), 4 x 4 (2D), 1 x 2 x 4 (3D, 3d/main.cu:21-23).
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
+
 #include "engine.h"
 
 namespace lora {
+
+typedef double d2v __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -117,6 +121,35 @@ hipError_t launch_halo(const Plan &p, void *dst, const void *src, int mode, hipS
     else
         hipLaunchKernelGGL(halo_kernel<double>, dim3(blocks), dim3(256), 0, s, static_cast<double *>(dst),
                            static_cast<const double *>(src), a, mode, total);
+    return hipGetLastError();
+}
+
+// A rows x cols block of 8-byte elements between two strided arrays: the pack / unpack of a block decomposition's column
+// ghost zones (lorastencil_amd/blocks.py).  A slab's ghost rows are one contiguous piece the sweep kernels read
+// in place; a block's ghost COLUMNS are `cols` elements out of every row.  One lane per 16 bytes where both sides allow
+// it (even cols, even leading dimensions and offsets: always the case for the driver's even ghost widths), else 8.
+namespace {
+template <typename V>
+__global__ void copy_block_kernel(V *__restrict__ dst, long dst_ld, const V *__restrict__ src, long src_ld, long rows, long cols) {
+    const long total = rows * cols;
+    for (long k = (long) blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long) gridDim.x * blockDim.x) {
+        const long r = k / cols, c = k - r * cols;
+        dst[r * dst_ld + c] = src[r * src_ld + c];
+    }
+}
+}  // namespace
+
+hipError_t launch_copy_block(double *dst, long dst_ld, const double *src, long src_ld, long rows, long cols, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    const bool wide = !((cols | dst_ld | src_ld) & 1) && !((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15);
+    const long total = wide ? rows * cols / 2 : rows * cols;
+    const long want = (total + 255) / 256;
+    const int blocks = (int) (want > 8192 ? 8192 : want);
+    if (wide)
+        hipLaunchKernelGGL(copy_block_kernel<d2v>, dim3(blocks), dim3(256), 0, s, reinterpret_cast<d2v *>(dst), dst_ld / 2,
+                           reinterpret_cast<const d2v *>(src), src_ld / 2, rows, cols / 2);
+    else
+        hipLaunchKernelGGL(copy_block_kernel<double>, dim3(blocks), dim3(256), 0, s, dst, dst_ld, src, src_ld, rows, cols);
     return hipGetLastError();
 }
 
