@@ -125,94 +125,175 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
         in1[r] = row_in && (unsigned) (col + 1) < (unsigned) a.n;
     }
 
-    double a1[K][4][2], a0[K][4][2];  // per level: the plane at hand (dz = 0, 1 taps in) / the plane above (dz = 0 tap in)
+    // Per level and point three sums rotate through three register slots, one step (= plane) per turn; in a step of
+    // phase P (= p mod 3, a compile-time constant of the step's copy):
+    //   acc[l][P]        the plane at hand (dz = 0, 1 taps in); the dz = 2 tap completes it IN PLACE, and it is then the
+    //                    input plane of level l + 1 for the rest of the step (level K: the output, stored next step)
+    //   acc[l][(P+1)%3]  the plane above (dz = 0 tap in); takes its dz = 1 taps in place
+    //   acc[l][(P+2)%3]  free (last step's completed plane, consumed by then): opened with the dz = 0 tap
+    // With the roles turning instead of the values no register is ever copied (the two-slot form of this loop spent a fifth
+    // of its vector instructions on v_mov_b64).
+    double acc[K][3][4][2];
 #pragma unroll
     for (int l = 0; l < K; ++l)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a1[l][r][0] = a1[l][r][1] = a0[l][r][0] = a0[l][r][1] = 0.0;
-    d2 nxt[4], outv[4];
-    auto load_plane = [&](int p) {
+        for (int q = 0; q < 3; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[l][q][r][0] = acc[l][q][r][1] = 0.0;
+    d2 nxt[3][4];  // input planes in flight: plane p in slot p mod 3 (two are live at a time)
+    auto load_plane = [&](int p, d2 (&dst)[4]) {
         const double *src = a.in + (long) min(max(k0 - K + p + 1, 0), a.h + 1) * a.plane + pc;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) nxt[r] = *reinterpret_cast<const d2 *>(src + rowoff[r]);  // (compiler-tracked: see step())
+        for (int r = 0; r < 4; ++r) dst[r] = *reinterpret_cast<const d2 *>(src + rowoff[r]);  // (compiler-tracked: see step())
     };
-    load_plane(0);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) outv[r] = (d2){0.0, 0.0};
+    load_plane(0, nxt[0]);
 
-    auto step = [&](const int p, auto edge_tag) {
+    auto step = [&](const int p, auto phase_tag, auto edge_tag) {
+        constexpr int P = decltype(phase_tag)::value, P1 = (P + 1) % 3, P2 = (P + 2) % 3;
         constexpr bool EDGE = decltype(edge_tag)::value;
-        // Everything issued one step ago has had a whole step to complete: the loads of plane p (and of its halo values), the
-        // stores of the output plane before last.  The plane loads are plain loads on purpose: the compiler waits for them
-        // where they are first used -- right here, and with stores outstanding beside them it waits for vmcnt(0), which is
-        // what this step wants anyway -- and it never copies or spills a register whose load is still in flight (loads
-        // issued and waited for in separate asm statements gave wrong planes at 256 VGPRs).  The explicit wait is for the
-        // LDS-DMA of the halo values, whose consumers (ds_read) the compiler does not connect to it.
+        // Everything issued one step ago has had a whole step to complete: the loads of plane p, the stores of the output
+        // plane before last.  The plane loads are plain loads on purpose: the compiler waits for them where they are first
+        // used -- right here, and with stores outstanding beside them it waits for vmcnt(0), which is what this step wants
+        // anyway -- and it never copies or spills a register whose load is still in flight (loads issued and waited for in
+        // separate asm statements gave wrong planes at 256 VGPRs).
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         {
-            const int o = p - 2 * K - 1;  // the output plane completed in the previous step
+            const int o = p - 2 * K - 1;  // the output plane completed in the previous step: level K's slot of phase P - 1
             const bool live = o >= 0 && o < zc;
             double *const dst = a.out + (long) (k0 + max(o, 0) + 1) * a.plane + 4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     dst + rowoff[r], 0, (live && st_row[r]) ? (unsigned) a.n * 8u : 0u, 0x00020000);
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, outv[r]), rs, st_off, 0, 0);
+                const d2 ov = {acc[K - 1][P2][r][0], acc[K - 1][P2][r][1]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs, st_off, 0, 0);
             }
         }
-        double v[4][2];
+        double v0[4][2];  // the input plane of level 1
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            v[r][0] = nxt[r].x;
-            v[r][1] = nxt[r].y;
+            v0[r][0] = nxt[P][r].x;
+            v0[r][1] = nxt[P][r].y;
         }
-        load_plane(p + 1);
+        load_plane(p + 1, nxt[P1]);
         if (EDGE && K > 2) {
             // The value a level-2 cell outside the interior is forced to is the source buffer's own value there (while fused
             // launches run every buffer carries buffer 0's halo) -- the very cell this lane holds of the INPUT plane with the
             // same index, which it took in two steps ago: a private delay line of three planes in LDS, no memory request.
 #pragma unroll
-            for (int r = 0; r < 4; ++r) *reinterpret_cast<d2 *>(&delay[p % 3][wv][r][2 * lane]) = (d2){v[r][0], v[r][1]};
+            for (int r = 0; r < 4; ++r) *reinterpret_cast<d2 *>(&delay[P][wv][r][2 * lane]) = (d2){v0[r][0], v0[r][1]};
         }
-#pragma unroll
-        for (int l = 0; l < K; ++l) {
-            // level l + 1 from the plane of level l in v.  Rows above / below this wave's four: the neighbours' edge rows.
-            *reinterpret_cast<d2 *>(&edge_rows[l][wv][0][2 * lane]) = (d2){v[0][0], v[0][1]};
-            *reinterpret_cast<d2 *>(&edge_rows[l][wv][1][2 * lane]) = (d2){v[3][0], v[3][1]};
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            const d2 vu = *reinterpret_cast<const d2 *>(&edge_rows[l][up][1][2 * lane]);
-            const d2 vd = *reinterpret_cast<const d2 *>(&edge_rows[l][dn][0][2 * lane]);
-            double nv[4][2];
-            if constexpr (TAPSET == TAPS3D_STAR) {
+        // the plane of level l + 1 just completed, k0 - K + p - (l + 1): its cells outside the interior are forced
+        auto force = [&](const int l) {
+            if (EDGE && l + 1 < K) {
+                const int z = k0 - K + p - (l + 1);
+                const bool z_in = (unsigned) z < (unsigned) a.h;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const double xl = lane_below(v[r][1]), xr = lane_above(v[r][0]);
-                    const double u0 = r == 0 ? vu.x : v[r - 1][0], u1 = r == 0 ? vu.y : v[r - 1][1];
-                    const double b0 = r == 3 ? vd.x : v[r + 1][0], b1 = r == 3 ? vd.y : v[r + 1][1];
-                    // the dz = 2 tap completes the plane below; the dz = 1 taps in (dy, dx) order go to the plane at hand;
-                    // the dz = 0 tap opens the plane above (fma with a literal zero: what adding to a cleared sum gives)
-                    nv[r][0] = fma(W.w[22], v[r][0], a1[l][r][0]);
-                    nv[r][1] = fma(W.w[22], v[r][1], a1[l][r][1]);
-                    double s0 = fma(W.w[10], u0, a0[l][r][0]), s1 = fma(W.w[10], u1, a0[l][r][1]);
-                    s0 = fma(W.w[12], xl, s0);
-                    s1 = fma(W.w[12], v[r][0], s1);
-                    s0 = fma(W.w[13], v[r][0], s0);
-                    s1 = fma(W.w[13], v[r][1], s1);
-                    s0 = fma(W.w[14], v[r][1], s0);
-                    s1 = fma(W.w[14], xr, s1);
-                    a1[l][r][0] = fma(W.w[16], b0, s0);
-                    a1[l][r][1] = fma(W.w[16], b1, s1);
-                    a0[l][r][0] = fma(W.w[4], v[r][0], 0.0);
-                    a0[l][r][1] = fma(W.w[4], v[r][1], 0.0);
+                    d2 hv = {0.0, 0.0};
+                    if ((l + 1) % 2 == 0) hv = *reinterpret_cast<const d2 *>(&delay[P1][wv][r][2 * lane]);  // written in step p - 2
+                    acc[l][P][r][0] = (z_in && in0[r]) ? acc[l][P][r][0] : hv.x;
+                    acc[l][P][r][1] = (z_in && in1[r]) ? acc[l][P][r][1] : hv.y;
                 }
-            } else {
-                // separable taps w = a(z) b(y) c(x), W.w[0..2] = c, [3..5] = b, [6..8] = a (planes_3d.h, scatter_plane_sep):
-                // x-pass over the six rows, y-pass, then the three z contributions
+            }
+        };
+        if constexpr (TAPSET == TAPS3D_STAR) {
+            // The star's dz = 2 tap is the centre point alone: the planes of ALL levels complete in a chain of K x 8
+            // multiply-adds with no neighbour in it, before any exchange.  So the step has ONE exchange: every level's two
+            // edge rows are published together, and while they travel the wave does everything that needs no other wave's
+            // row (rows 1 .. 3 of the lane's four, but for row 3's last tap); behind the barrier come row 0 and that tap.
+            // A second barrier right before the publication keeps it behind the last step's reads.
+#pragma unroll
+            for (int l = 0; l < K; ++l) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    acc[l][P][r][0] = fma(W.w[22], l == 0 ? v0[r][0] : acc[l - 1][P][r][0], acc[l][P][r][0]);
+                    acc[l][P][r][1] = fma(W.w[22], l == 0 ? v0[r][1] : acc[l - 1][P][r][1], acc[l][P][r][1]);
+                }
+                force(l);
+            }
+            // nobody publishes this step's rows before everybody has read the last step's
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+            for (int l = 0; l < K; ++l) {
+                const double(&in)[4][2] = l == 0 ? v0 : acc[l - 1][P];
+                *reinterpret_cast<d2 *>(&edge_rows[l][wv][0][2 * lane]) = (d2){in[0][0], in[0][1]};
+                *reinterpret_cast<d2 *>(&edge_rows[l][wv][1][2 * lane]) = (d2){in[3][0], in[3][1]};
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // taps in the oracle's order per accumulator: (dz = 1) dy = -1, dx = -1, 0, +1, dy = +1; then dz = 0 opens the next
+            auto own_rows = [&](const int l) {
+                const double(&in)[4][2] = l == 0 ? v0 : acc[l - 1][P];
+#pragma unroll
+                for (int r = 1; r < 4; ++r) {
+                    const double xl = lane_below(in[r][1]), xr = lane_above(in[r][0]);
+                    double s0 = fma(W.w[10], in[r - 1][0], acc[l][P1][r][0]), s1 = fma(W.w[10], in[r - 1][1], acc[l][P1][r][1]);
+                    s0 = fma(W.w[12], xl, s0);
+                    s1 = fma(W.w[12], in[r][0], s1);
+                    s0 = fma(W.w[13], in[r][0], s0);
+                    s1 = fma(W.w[13], in[r][1], s1);
+                    s0 = fma(W.w[14], in[r][1], s0);
+                    s1 = fma(W.w[14], xr, s1);
+                    if (r < 3) {
+                        s0 = fma(W.w[16], in[r + 1][0], s0);
+                        s1 = fma(W.w[16], in[r + 1][1], s1);
+                    }
+                    acc[l][P1][r][0] = s0;
+                    acc[l][P1][r][1] = s1;
+                    acc[l][P2][r][0] = fma(W.w[4], in[r][0], 0.0);
+                    acc[l][P2][r][1] = fma(W.w[4], in[r][1], 0.0);
+                }
+            };
+#pragma unroll
+            for (int l = 0; l + 1 < K; ++l) own_rows(l);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            d2 vu[K], vd[K];
+#pragma unroll
+            for (int l = 0; l < K; ++l) {
+                vu[l] = *reinterpret_cast<const d2 *>(&edge_rows[l][up][1][2 * lane]);
+                vd[l] = *reinterpret_cast<const d2 *>(&edge_rows[l][dn][0][2 * lane]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            own_rows(K - 1);  // (while the neighbours' rows arrive)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int l = 0; l < K; ++l) {
+                const double(&in)[4][2] = l == 0 ? v0 : acc[l - 1][P];
+                const double xl = lane_below(in[0][1]), xr = lane_above(in[0][0]);
+                double s0 = fma(W.w[10], vu[l].x, acc[l][P1][0][0]), s1 = fma(W.w[10], vu[l].y, acc[l][P1][0][1]);
+                s0 = fma(W.w[12], xl, s0);
+                s1 = fma(W.w[12], in[0][0], s1);
+                s0 = fma(W.w[13], in[0][0], s0);
+                s1 = fma(W.w[13], in[0][1], s1);
+                s0 = fma(W.w[14], in[0][1], s0);
+                s1 = fma(W.w[14], xr, s1);
+                acc[l][P1][0][0] = fma(W.w[16], in[1][0], s0);
+                acc[l][P1][0][1] = fma(W.w[16], in[1][1], s1);
+                acc[l][P2][0][0] = fma(W.w[4], in[0][0], 0.0);
+                acc[l][P2][0][1] = fma(W.w[4], in[0][1], 0.0);
+                acc[l][P1][3][0] = fma(W.w[16], vd[l].x, acc[l][P1][3][0]);
+                acc[l][P1][3][1] = fma(W.w[16], vd[l].y, acc[l][P1][3][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // separable taps w = a(z) b(y) c(x), W.w[0..2] = c, [3..5] = b, [6..8] = a (planes_3d.h, scatter_plane_sep):
+            // x-pass over the six rows, y-pass, then the three z contributions.  The dz = 2 contribution needs the whole
+            // (x, y) neighbourhood, so here the levels do follow each other through an exchange each.
+#pragma unroll
+            for (int l = 0; l < K; ++l) {
+                const double(&in)[4][2] = l == 0 ? v0 : acc[l - 1][P];
+                *reinterpret_cast<d2 *>(&edge_rows[l][wv][0][2 * lane]) = (d2){in[0][0], in[0][1]};
+                *reinterpret_cast<d2 *>(&edge_rows[l][wv][1][2 * lane]) = (d2){in[3][0], in[3][1]};
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const d2 vu = *reinterpret_cast<const d2 *>(&edge_rows[l][up][1][2 * lane]);
+                const d2 vd = *reinterpret_cast<const d2 *>(&edge_rows[l][dn][0][2 * lane]);
                 double t0[6], t1[6];
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const double c0 = j == 0 ? vu.x : (j == 5 ? vd.x : v[j - 1][0]);
-                    const double c1 = j == 0 ? vu.y : (j == 5 ? vd.y : v[j - 1][1]);
+                    const double c0 = j == 0 ? vu.x : (j == 5 ? vd.x : in[j == 0 || j == 5 ? 0 : j - 1][0]);
+                    const double c1 = j == 0 ? vu.y : (j == 5 ? vd.y : in[j == 0 || j == 5 ? 0 : j - 1][1]);
                     const double xl = lane_below(c1), xr = lane_above(c0);
                     t0[j] = fma(W.w[2], c1, fma(W.w[1], c0, W.w[0] * xl));
                     t1[j] = fma(W.w[2], xr, fma(W.w[1], c1, W.w[0] * c0));
@@ -221,47 +302,35 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
                 for (int r = 0; r < 4; ++r) {
                     const double u0 = fma(W.w[5], t0[r + 2], fma(W.w[4], t0[r + 1], W.w[3] * t0[r]));
                     const double u1 = fma(W.w[5], t1[r + 2], fma(W.w[4], t1[r + 1], W.w[3] * t1[r]));
-                    nv[r][0] = fma(W.w[8], u0, a1[l][r][0]);
-                    nv[r][1] = fma(W.w[8], u1, a1[l][r][1]);
-                    a1[l][r][0] = fma(W.w[7], u0, a0[l][r][0]);
-                    a1[l][r][1] = fma(W.w[7], u1, a0[l][r][1]);
-                    a0[l][r][0] = W.w[6] * u0;
-                    a0[l][r][1] = W.w[6] * u1;
+                    acc[l][P][r][0] = fma(W.w[8], u0, acc[l][P][r][0]);
+                    acc[l][P][r][1] = fma(W.w[8], u1, acc[l][P][r][1]);
+                    acc[l][P1][r][0] = fma(W.w[7], u0, acc[l][P1][r][0]);
+                    acc[l][P1][r][1] = fma(W.w[7], u1, acc[l][P1][r][1]);
+                    acc[l][P2][r][0] = W.w[6] * u0;
+                    acc[l][P2][r][1] = W.w[6] * u1;
                 }
-            }
-            if (EDGE && l + 1 < K) {
-                // the plane of level l + 1 just completed: k0 - K + p - (l + 1); its cells outside the interior are forced
-                const int z = k0 - K + p - (l + 1);
-                const bool z_in = (unsigned) z < (unsigned) a.h;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    d2 hv = {0.0, 0.0};
-                    if ((l + 1) % 2 == 0) hv = *reinterpret_cast<const d2 *>(&delay[(p + 1) % 3][wv][r][2 * lane]);  // written in step p - 2
-                    nv[r][0] = (z_in && in0[r]) ? nv[r][0] : hv.x;
-                    nv[r][1] = (z_in && in1[r]) ? nv[r][1] : hv.y;
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v[r][0] = nv[r][0];
-                v[r][1] = nv[r][1];
+                force(l);
             }
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) outv[r] = (d2){v[r][0], v[r][1]};
     };
 
     // Steps whose intermediate planes can lie outside the z range: p < p1 (below plane 0) and p >= p2 (beyond plane h - 1;
     // two steps early, because the delay line must hold the planes an EDGE step looks back at).  Tiles on the rim in x / y
-    // run the EDGE copy throughout.
-    const int steps = zc + 2 * K + 1;
+    // run the EDGE copy throughout.  Steps come in turns of three (one per phase); the EDGE ranges are widened to whole
+    // turns, and a chunk runs up to two steps past its last plane (loads clamped, stores switched off).
+    const int steps = zc + 2 * K + 1, turns = (steps + 2) / 3;
     int p1 = min(max(2 * K - k0, 0), steps), p2 = min(max(a.h - k0 + K - 1, p1), steps);
     if (xy_rim) p1 = steps;
-    int p = 0;
-    for (; p < p1; ++p) step(p, std::true_type{});
-    for (; p < p2; ++p) step(p, std::false_type{});
-    for (; p < steps; ++p) step(p, std::true_type{});
-    // drain: LDS-DMA in flight would land in the LDS of the next workgroup
+    const int t1 = min((p1 + 2) / 3, turns), t2 = min(max(p2 / 3, t1), turns);
+    auto turn = [&](const int p, auto edge_tag) {
+        step(p, std::integral_constant<int, 0>{}, edge_tag);
+        step(p + 1, std::integral_constant<int, 1>{}, edge_tag);
+        step(p + 2, std::integral_constant<int, 2>{}, edge_tag);
+    };
+    int t = 0;
+    for (; t < t1; ++t) turn(3 * t, std::true_type{});
+    for (; t < t2; ++t) turn(3 * t, std::false_type{});
+    for (; t < turns; ++t) turn(3 * t, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
