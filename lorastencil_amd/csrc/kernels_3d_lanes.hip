@@ -42,6 +42,13 @@
 
 #include "device_common.h"
 
+// Ablation switches for tools/probes/lanes3_ablate.hip (timing only -- results are wrong with any of them set):
+// 1 no barriers, 2 no stores, 4 no plane loads after the first, 8 no cross-lane moves, 16 no EDGE steps, 32 only EDGE steps,
+// 64 (star) only the chain of dz = 2 taps: the memory pattern with next to no arithmetic
+#ifndef LORA_L3_ABLATE
+#define LORA_L3_ABLATE 0
+#endif
+
 namespace lora {
 
 namespace {
@@ -63,12 +70,14 @@ struct ArgsL3 {
 };
 
 __device__ __forceinline__ double lane_below(double v) {  // the value lane i - 1 holds (0 in lane 0)
+    if constexpr (LORA_L3_ABLATE & 8) return v;
     const long long b = __builtin_bit_cast(long long, v);
     const int lo = __builtin_amdgcn_update_dpp(0, (int) b, 0x138, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), 0x138, 0xf, 0xf, true);
     return __builtin_bit_cast(double, ((long long) hi << 32) | (unsigned) lo);
 }
 __device__ __forceinline__ double lane_above(double v) {  // the value lane i + 1 holds (0 in lane 63)
+    if constexpr (LORA_L3_ABLATE & 8) return v;
     const long long b = __builtin_bit_cast(long long, v);
     const int lo = __builtin_amdgcn_update_dpp(0, (int) b, 0x130, 0xf, 0xf, true);
     const int hi = __builtin_amdgcn_update_dpp(0, (int) (b >> 32), 0x130, 0xf, 0xf, true);
@@ -88,10 +97,37 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
-    const int per_chunk = a.tiles_x * a.tiles_y;
-    const int chunk = lin / per_chunk;
-    const int rem = lin - chunk * per_chunk;
-    const int ty = rem / a.tiles_x, tx = rem - ty * a.tiles_x;
+    // workgroup -> (chunk, tile): the tiles on the rim of the grid first -- they run the slower EDGE steps throughout, and
+    // with the long workgroups dispatched first the short ones even out the end of the launch
+    const int TX = a.tiles_x, TY = a.tiles_y, chunks = (a.z_end - a.z_begin + a.zc - 1) / a.zc;
+    int chunk, tx, ty;
+    if (TX < 3 || TY < 3) {
+        const int per_chunk = TX * TY;
+        chunk = lin / per_chunk;
+        const int rem = lin - chunk * per_chunk;
+        ty = rem / TX;
+        tx = rem - ty * TX;
+    } else {
+        const int rim = 2 * TX + 2 * (TY - 2), inner = (TX - 2) * (TY - 2);
+        if (lin < rim * chunks) {
+            chunk = lin / rim;
+            const int idx = lin - chunk * rim;
+            if (idx < 2 * TX) {
+                ty = idx < TX ? 0 : TY - 1;
+                tx = idx < TX ? idx : idx - TX;
+            } else {
+                const int k = idx - 2 * TX;
+                ty = 1 + (k >> 1);
+                tx = (k & 1) ? TX - 1 : 0;
+            }
+        } else {
+            const int l2 = lin - rim * chunks;
+            chunk = l2 / inner;
+            const int idx = l2 - chunk * inner;
+            ty = 1 + idx / (TX - 2);
+            tx = 1 + idx - (ty - 1) * (TX - 2);
+        }
+    }
     const int k0 = a.z_begin + chunk * a.zc;
     const int zc = min(a.zc, a.z_end - k0);
     const int X0 = tx * kOutW - 4, Y0 = ty * OH - K;  // interior coordinates of the tile's first column / row
@@ -103,6 +139,10 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
 #pragma unroll
     for (int r = 0; r < 4; ++r) rowoff[r] = (long) min(max(Y0 + 4 * wv + r + 2, 0), a.m + 3) * a.ld;
     const int up = max(wv - 1, 0), dn = min(wv + 1, NW - 1);  // (the tile's outermost rows are never valid beyond level 0)
+    // (An L2 prefetch of the planes two or three steps ahead -- one 4-byte LDS-DMA per lane and step touching the wave's
+    // 64-byte pieces, landing in an LDS row nobody reads -- made the launch 5-12 % SLOWER, with and without the arithmetic:
+    // the launch is bound by the bytes this access pattern moves, 2.7 GB at ~4.9 TB/s, not by the latency of its loads.
+    // tools/probes/lanes3_ablate.hip, profiles/r03_lanes3d_ablation.txt.)
 
     // stores: lanes 2 .. 61 write interior columns col, col + 1 of rows K .. 4 NW - K - 1 of the tile; the descriptor's
     // range check drops what lies beyond the row (also the second half of the last pair when n is odd)
@@ -166,7 +206,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     dst + rowoff[r], 0, (live && st_row[r]) ? (unsigned) a.n * 8u : 0u, 0x00020000);
                 const d2 ov = {acc[K - 1][P2][r][0], acc[K - 1][P2][r][1]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs, st_off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs, (LORA_L3_ABLATE & 2) ? 0x80000000u : st_off, 0, 0);
             }
         }
         double v0[4][2];  // the input plane of level 1
@@ -175,7 +215,12 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
             v0[r][0] = nxt[P][r].x;
             v0[r][1] = nxt[P][r].y;
         }
-        load_plane(p + 1, nxt[P1]);
+        if constexpr (LORA_L3_ABLATE & 4) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nxt[P1][r] = nxt[P][r] + (d2){1e-9, 1e-9};
+        } else {
+            load_plane(p + 1, nxt[P1]);
+        }
         if (EDGE && K > 2) {
             // The value a level-2 cell outside the interior is forced to is the source buffer's own value there (while fused
             // launches run every buffer carries buffer 0's halo) -- the very cell this lane holds of the INPUT plane with the
@@ -214,7 +259,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
             }
             // nobody publishes this step's rows before everybody has read the last step's
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_barrier" ::: "memory");
+            if constexpr (!(LORA_L3_ABLATE & 1)) asm volatile("s_barrier" ::: "memory");
 #pragma unroll
             for (int l = 0; l < K; ++l) {
                 const double(&in)[4][2] = l == 0 ? v0 : acc[l - 1][P];
@@ -224,6 +269,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
             __builtin_amdgcn_sched_barrier(0);
             // taps in the oracle's order per accumulator: (dz = 1) dy = -1, dx = -1, 0, +1, dy = +1; then dz = 0 opens the next
             auto own_rows = [&](const int l) {
+                if constexpr (LORA_L3_ABLATE & 64) return;
                 const double(&in)[4][2] = l == 0 ? v0 : acc[l - 1][P];
 #pragma unroll
                 for (int r = 1; r < 4; ++r) {
@@ -248,7 +294,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
 #pragma unroll
             for (int l = 0; l + 1 < K; ++l) own_rows(l);
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            if constexpr (!(LORA_L3_ABLATE & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             d2 vu[K], vd[K];
 #pragma unroll
             for (int l = 0; l < K; ++l) {
@@ -259,7 +305,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
             own_rows(K - 1);  // (while the neighbours' rows arrive)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int l = 0; l < K; ++l) {
+            for (int l = 0; l < ((LORA_L3_ABLATE & 64) ? 0 : K); ++l) {
                 const double(&in)[4][2] = l == 0 ? v0 : acc[l - 1][P];
                 const double xl = lane_below(in[0][1]), xr = lane_above(in[0][0]);
                 double s0 = fma(W.w[10], vu[l].x, acc[l][P1][0][0]), s1 = fma(W.w[10], vu[l].y, acc[l][P1][0][1]);
@@ -279,25 +325,30 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
             __builtin_amdgcn_sched_barrier(0);
         } else {
             // separable taps w = a(z) b(y) c(x), W.w[0..2] = c, [3..5] = b, [6..8] = a (planes_3d.h, scatter_plane_sep):
-            // x-pass over the six rows, y-pass, then the three z contributions.  The dz = 2 contribution needs the whole
-            // (x, y) neighbourhood, so here the levels do follow each other through an exchange each.
+            // x-pass, y-pass, then the three z contributions.  The dz = 2 contribution needs the whole (x, y) neighbourhood,
+            // so here the levels do follow each other through an exchange each.  What a wave publishes is the x-PASSED
+            // form of its first and last row (the same multiply-adds on the same cells whoever does them): the neighbours'
+            // rows then cost no x-pass of their own, and the wave's own x-pass runs ahead of the barrier.
 #pragma unroll
             for (int l = 0; l < K; ++l) {
                 const double(&in)[4][2] = l == 0 ? v0 : acc[l - 1][P];
-                *reinterpret_cast<d2 *>(&edge_rows[l][wv][0][2 * lane]) = (d2){in[0][0], in[0][1]};
-                *reinterpret_cast<d2 *>(&edge_rows[l][wv][1][2 * lane]) = (d2){in[3][0], in[3][1]};
-                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-                const d2 vu = *reinterpret_cast<const d2 *>(&edge_rows[l][up][1][2 * lane]);
-                const d2 vd = *reinterpret_cast<const d2 *>(&edge_rows[l][dn][0][2 * lane]);
                 double t0[6], t1[6];
 #pragma unroll
-                for (int j = 0; j < 6; ++j) {
-                    const double c0 = j == 0 ? vu.x : (j == 5 ? vd.x : in[j == 0 || j == 5 ? 0 : j - 1][0]);
-                    const double c1 = j == 0 ? vu.y : (j == 5 ? vd.y : in[j == 0 || j == 5 ? 0 : j - 1][1]);
+                for (int j = 1; j < 5; ++j) {
+                    const double c0 = in[j - 1][0], c1 = in[j - 1][1];
                     const double xl = lane_below(c1), xr = lane_above(c0);
                     t0[j] = fma(W.w[2], c1, fma(W.w[1], c0, W.w[0] * xl));
                     t1[j] = fma(W.w[2], xr, fma(W.w[1], c1, W.w[0] * c0));
                 }
+                *reinterpret_cast<d2 *>(&edge_rows[l][wv][0][2 * lane]) = (d2){t0[1], t1[1]};
+                *reinterpret_cast<d2 *>(&edge_rows[l][wv][1][2 * lane]) = (d2){t0[4], t1[4]};
+                if constexpr (!(LORA_L3_ABLATE & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const d2 vu = *reinterpret_cast<const d2 *>(&edge_rows[l][up][1][2 * lane]);
+                const d2 vd = *reinterpret_cast<const d2 *>(&edge_rows[l][dn][0][2 * lane]);
+                t0[0] = vu.x;
+                t1[0] = vu.y;
+                t0[5] = vd.x;
+                t1[5] = vd.y;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const double u0 = fma(W.w[5], t0[r + 2], fma(W.w[4], t0[r + 1], W.w[3] * t0[r]));
@@ -321,6 +372,8 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
     const int steps = zc + 2 * K + 1, turns = (steps + 2) / 3;
     int p1 = min(max(2 * K - k0, 0), steps), p2 = min(max(a.h - k0 + K - 1, p1), steps);
     if (xy_rim) p1 = steps;
+    if (LORA_L3_ABLATE & 16) p1 = 0, p2 = steps;
+    if (LORA_L3_ABLATE & 32) p1 = steps;
     const int t1 = min((p1 + 2) / 3, turns), t2 = min(max(p2 / 3, t1), turns);
     auto turn = [&](const int p, auto edge_tag) {
         step(p, std::integral_constant<int, 0>{}, edge_tag);
