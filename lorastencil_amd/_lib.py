@@ -86,7 +86,7 @@ class SlabInfo(ctypes.Structure):
                 ("exchanges", ctypes.c_long), ("local_bytes", ctypes.c_size_t)]
 
 
-SLAB_NO_OVERLAP, SLAB_NO_DEFER, SLAB_NO_FUSION, SLAB_RING_OF_ONE = 1, 2, 4, 8
+SLAB_NO_OVERLAP, SLAB_NO_DEFER, SLAB_NO_FUSION, SLAB_RING_OF_ONE, SLAB_OVERLAP = 1, 2, 4, 8, 16
 
 
 class Rng(ctypes.Structure):

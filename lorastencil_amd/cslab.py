@@ -12,7 +12,7 @@ from typing import Sequence
 import numpy as np
 
 from . import _lib, ops
-from ._lib import SLAB_NO_DEFER, SLAB_NO_FUSION, SLAB_NO_OVERLAP, SLAB_RING_OF_ONE, check  # noqa: F401
+from ._lib import SLAB_NO_DEFER, SLAB_NO_FUSION, SLAB_NO_OVERLAP, SLAB_OVERLAP, SLAB_RING_OF_ONE, check  # noqa: F401
 
 
 def loopback_comms(nranks: int):

@@ -318,6 +318,18 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
             }
         };
         int g = 0;
+        if constexpr (STAGE > 0) {
+            // Level l needs its first row complete in step 7 l - 1 and starts accumulating it six steps earlier: the levels
+            // of stage s have nothing to do in the first s KL groups of a chunk.  Their waves only keep the barrier count
+            // there, and the stages below have the vector pipe to themselves (a chunk costs about rows + 30 steps instead
+            // of rows + 41 at K = 6: what thin shares of a multi-GPU run and small grids lose most).
+            const int idle = min(STAGE * KL, groups);
+            for (int q = 0; q < 7 * idle; ++q) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            g = idle;
+        }
         for (; g < g1; ++g) {
             slice();
             group(7 * g, std::true_type{});

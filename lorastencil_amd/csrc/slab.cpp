@@ -483,7 +483,14 @@ int lora_slab_create(lora_slab **out, const lora_slab_desc *d, const lora_slab_c
     s->h0 = halo0_of(nd);
     s->radius = radius_of(nd);
     s->dirichlet = d->boundary == LORA_BC_DIRICHLET;
-    s->overlap = !(d->flags & LORA_SLAB_NO_OVERLAP);
+    // Boundary strips first is the default in 1D and 3D.  In 2D the whole slab goes in one launch unless LORA_SLAB_OVERLAP
+    // asks for the strips: the six-sweep kernel runs ONE round of workgroups sized to its region, and a chunk pays 41
+    // warm-up steps whatever its length, so two 32-row strips cost two third-length launches on a nearly empty chip
+    // (ring of one over RCCL, GStencils/s per rank, strips + deferred wait / whole slab + deferred wait / whole slab +
+    // wait at once: 2048-row share 789 / 879 / 930, 4096 rows 973 / 1114 / 1131, 8192 rows 1234 / 1251 / 1288 at a
+    // refresh every 4 launches -- tools/cslab_overlap.py, profiles/r03_cslab_schedule_sweep.jsonl).  The deferred wait
+    // stays: it is what hides a real link behind the next launch's interior.
+    s->overlap = nd == 2 ? (d->flags & LORA_SLAB_OVERLAP) != 0 : !(d->flags & LORA_SLAB_NO_OVERLAP);
     s->defer_wait = !(d->flags & LORA_SLAB_NO_DEFER);
     if (comm) {
         s->comm = *comm;
@@ -555,9 +562,11 @@ int lora_slab_create(lora_slab **out, const lora_slab_desc *d, const lora_slab_c
     s->need = s->radius * apps;
     int every = d->exchange_every;
     if (every <= 0) {
-        // refresh as rarely as keeps the redundant ghost sweeps within ~10 % of the thinnest slab
+        // refresh as rarely as keeps the redundant ghost sweeps within ~10 % of the thinnest slab (2D: ~3 % -- six sweeps
+        // per launch make the zones 18 rows per launch deep, and every launch sweeps all of them: at 8 launches a 2048-row
+        // share carries 14 % of ghost rows; 4 measured best on 2048- and 4096-row shares, 8 on 8192)
         every = 8;
-        while (every > 1 && (every - 1) * s->need > 0.1 * thinnest) every /= 2;
+        while (every > 1 && (every - 1) * s->need > (nd == 2 ? 0.03 : 0.1) * thinnest) every /= 2;
     }
     if (splitting) every = std::max(1, std::min(every, thinnest / s->need));
     if (splitting && thinnest < s->need) {

@@ -192,7 +192,7 @@ class SlabDriver:
     """Time-step driver of one rank's slab (reference driver semantics, 2d/gpu.cu:525-554, per slab)."""
 
     def __init__(self, shape, global_dims: Sequence[int], group=None, device=None, params=None, weights=None,
-                 stepper_factory: Callable[[SlabLayout], object] | None = None, overlap: bool = True,
+                 stepper_factory: Callable[[SlabLayout], object] | None = None, overlap: bool | None = None,
                  exchange_every: int | None = None, fused: bool | None = None, boundary_rows: int | None = None,
                  dtype="f64", boundary: str = "reference", ring_of_one: bool = False, options=None, variant=None):
         if boundary not in ("reference", "dirichlet", "periodic"):
@@ -246,8 +246,10 @@ class SlabDriver:
                 # refresh as rarely as keeps the redundant ghost sweeps (about (E - 1) x need rows per launch) within
                 # ~10 % of a slab: 8 launches for the 2D / 1D configurations, 4 for the thin 3D slabs of an 8-GPU run
                 # (ring of one over RCCL, 2048 x 16384 slab: E = 2 / 4 / 8 / 16 -> 492 / 535 / 553 / 534 GStencils/s)
+                # (2D: ~3 % -- at six sweeps per launch the zones are 18 rows per launch deep and every launch sweeps all
+                # of them; csrc/slab.cpp has the measurements)
                 exchange_every = 8
-                while exchange_every > 1 and (exchange_every - 1) * need > 0.1 * thinnest:
+                while exchange_every > 1 and (exchange_every - 1) * need > (0.03 if nd == 2 else 0.1) * thinnest:
                     exchange_every //= 2
             e = max(1, min(exchange_every, thinnest // need if split else exchange_every))
             if split and thinnest < need:
@@ -266,7 +268,9 @@ class SlabDriver:
             raise ValueError("slabs are thinner than the stencil radius")
         self.layout = layout
         self.radius = radius
-        self.overlap = overlap
+        # boundary strips first: the default in 1D / 3D; in 2D the whole slab goes in one launch (csrc/slab.cpp: a 32-row
+        # strip costs a third of a whole-slab launch of the six-sweep kernel) and only the deferred wait hides the link
+        self.overlap = (nd != 2) if overlap is None else bool(overlap)
         self.local_padded_shape = ops.padded_shape(sid, layout.local_dims)
         self.buf = [torch.zeros(self.local_padded_shape, dtype=self.torch_dtype, device=self.device) for _ in range(2)]
         if boundary_rows is None:

@@ -50,10 +50,11 @@ def test_slab_descriptor_validation(L):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,dims,nranks,times,every,flags,opts", [
-    ("star2d1r", (384, 256), 3, 11, 0, 0, {"steps_per_launch": 4}),     # four applications per launch: 4 + 4 + 2 + 1
+    ("star2d1r", (384, 256), 3, 11, 0, 16, {"steps_per_launch": 4}),    # four applications per launch: 4 + 4 + 2 + 1; strips first
     ("star2d1r", (768, 384), 2, 23, 2, 0, {"steps_per_launch": 4}),     # 24-row ghost zones refreshed every 2 launches, deferred waits
     ("star2d1r", (768, 384), 4, 16, 1, 1, None),     # six per launch (the default: workgroup-row kernel); no boundary-first overlap
     ("star2d1r", (768, 384), 4, 16, 2, 2, None),     # no deferred wait
+    ("star2d1r", (768, 384), 4, 22, 2, 16, None),    # boundary strips first (2D slabs go whole by default), deferred waits
     ("star2d1r", (768, 384), 3, 21, 1, 0, None),     # 6 + 6 + 6 + 2 + 1
     ("box2d3r", (300, 130), 3, 6, 3, 0, None),
     ("star2d3r", (256, 200), 2, 9, 1, 4, None),      # single sweeps only
