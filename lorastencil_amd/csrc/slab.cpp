@@ -562,11 +562,12 @@ int lora_slab_create(lora_slab **out, const lora_slab_desc *d, const lora_slab_c
     s->need = s->radius * apps;
     int every = d->exchange_every;
     if (every <= 0) {
-        // refresh as rarely as keeps the redundant ghost sweeps within ~10 % of the thinnest slab (2D: ~3 % -- six sweeps
-        // per launch make the zones 18 rows per launch deep, and every launch sweeps all of them: at 8 launches a 2048-row
-        // share carries 14 % of ghost rows; 4 measured best on 2048- and 4096-row shares, 8 on 8192)
+        // refresh as rarely as keeps the redundant ghost sweeps within ~10 % of the thinnest slab.  (2D, six sweeps per
+        // launch: a 2048-row share at 8 launches carries 14 % of ghost rows and still runs level with 4 launches / 7 % --
+        // 891 vs 888 GStencils/s here, 964 vs 919 in slab.py, whose exchanges cost more host time -- because every
+        // refresh also splits the launch after it in three for the deferred wait.)
         every = 8;
-        while (every > 1 && (every - 1) * s->need > (nd == 2 ? 0.03 : 0.1) * thinnest) every /= 2;
+        while (every > 1 && (every - 1) * s->need > 0.1 * thinnest) every /= 2;
     }
     if (splitting) every = std::max(1, std::min(every, thinnest / s->need));
     if (splitting && thinnest < s->need) {

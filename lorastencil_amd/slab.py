@@ -246,10 +246,8 @@ class SlabDriver:
                 # refresh as rarely as keeps the redundant ghost sweeps (about (E - 1) x need rows per launch) within
                 # ~10 % of a slab: 8 launches for the 2D / 1D configurations, 4 for the thin 3D slabs of an 8-GPU run
                 # (ring of one over RCCL, 2048 x 16384 slab: E = 2 / 4 / 8 / 16 -> 492 / 535 / 553 / 534 GStencils/s)
-                # (2D: ~3 % -- at six sweeps per launch the zones are 18 rows per launch deep and every launch sweeps all
-                # of them; csrc/slab.cpp has the measurements)
                 exchange_every = 8
-                while exchange_every > 1 and (exchange_every - 1) * need > (0.03 if nd == 2 else 0.1) * thinnest:
+                while exchange_every > 1 and (exchange_every - 1) * need > 0.1 * thinnest:
                     exchange_every //= 2
             e = max(1, min(exchange_every, thinnest // need if split else exchange_every))
             if split and thinnest < need:
