@@ -199,6 +199,19 @@ def test_plan_validation(L):
         p.step(0, 0)  # null buffers
 
 
+def test_block_copy_argument_checks(L):
+    """lora_copy_block_f64 (the pack / unpack kernel of the 2-D block decomposition): what it refuses before any launch"""
+    from lorastencil_amd import _lib
+
+    f = _lib.lib().lora_copy_block_f64
+    assert f(None, 8, 4096, 8, 2, 2, None) == _lib.LORA_EINVAL          # null destination
+    assert f(4096, 8, None, 8, 2, 2, None) == _lib.LORA_EINVAL          # null source
+    assert f(4096, 8, 8192, 8, -1, 2, None) == _lib.LORA_EINVAL         # negative extent
+    assert f(4096, 3, 8192, 8, 2, 4, None) == _lib.LORA_EINVAL          # rows overlap: leading dimension < columns
+    assert f(4100, 8, 8192, 8, 2, 2, None) == _lib.LORA_EUNSUPPORTED    # not 8-byte aligned
+    assert f(4096, 8, 8192, 8, 0, 0, None) == _lib.LORA_OK              # nothing to copy: no launch
+
+
 @pytest.mark.skipif(has_gpu(), reason="only meaningful on a box without a GPU")
 def test_compute_fails_loudly_without_gpu(L):
     from lorastencil_amd import _lib
