@@ -307,13 +307,13 @@ int lora_slab_comm_loopback(lora_slab_comm *out, int nranks);
 
 enum lora_slab_flags {
     LORA_SLAB_NO_OVERLAP = 1,  /* sweep the whole slab, then exchange (no boundary-first split); the default
-                                  for the 2D shapes: their six-sweep launch is ONE round of workgroups sized to
-                                  the region, so a 32-row boundary strip costs a third of a whole-slab launch
-                                  (measured: DESIGN section 6)                                                */
+                                  in 2D and 3D: a fused launch is ONE round of workgroups sized to its region,
+                                  so a thin boundary strip costs a third of a whole-slab launch (measured:
+                                  DESIGN section 6)                                                           */
     LORA_SLAB_NO_DEFER = 2,    /* wait for an exchange at the end of its launch instead of inside the next   */
     LORA_SLAB_NO_FUSION = 4,   /* single sweeps only                                                         */
     LORA_SLAB_OVERLAP = 16,    /* boundary strips first, exchange overlapped with the interior (the default in
-                                  1D and 3D; forces it in 2D)                                                 */
+                                  1D; forces it in 2D / 3D)                                                   */
     LORA_SLAB_RING_OF_ONE = 8  /* nranks == 1: the slab is its own neighbour (periodic along the split
                                   dimension) -- the complete exchange path on one GPU; with the reference boundary
                                   a rehearsal of one rank's share of an N-GPU run, not a physical result      */

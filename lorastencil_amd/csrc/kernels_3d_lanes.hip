@@ -39,6 +39,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 
 #include "device_common.h"
 
@@ -421,12 +422,16 @@ hipError_t launch_lanes_t(const Plan &p, const double *in, double *out, int begi
     a.tiles_x = (a.n + kOutW - 1) / kOutW;
     a.tiles_y = (a.m + OH - 1) / OH;
     const long tiles = (long) a.tiles_x * a.tiles_y;
-    // z-chunks.  A chunk re-reads 2 K planes and runs 2 K + 1 steps beyond its own, so chunks should be long; but
-    // workgroups on the grid's rim take longer than interior ones, and a single round of long chunks waits for the slowest
-    // (star3d1r 512^3, 110 tiles: chunks of 256 / 171 / 103 / 86 / 64 / 52 / 43 / 32 planes run at 775 / 655 / 728 / 801 /
-    // 810 / 800 / 783 / 691 GStencils/s; box3d1r 768^3, 224 tiles: 256 / 154 / 96 / 64 / 48 / 32: 751 / 767 / 842 / 805 /
-    // 781 / 690 -- gpurun_out/l3_cases.log).  Cost model: whole rounds of workgroups x steps per chunk, with a penalty for
-    // few rounds (nothing evens out the slow workgroups then); chunks of at least 8 K planes.
+    // z-chunks.  A chunk runs 2 K + 1 steps beyond its own planes, so chunks should be long; but the launch is bound by
+    // the bytes it moves, a round of workgroups (one per CU) takes steps x ~2.4 us whatever its kernels do, and a LAST,
+    // partly filled round is cheaper than a full one only down to about two thirds of it.  Cost model fitted to a sweep
+    // of chunk lengths (star3d1r 512^3, 110 tiles on 256 CUs, gpurun_out/lanes3_zc.txt + tools/thin3d_check.py;
+    // x = workgroups / CUs, time / 2.4 us / steps per chunk): x = 0.86 -> 1.00, 1.29 -> 1.78, 1.72 -> 1.99, 2.15 -> 2.70,
+    // 2.58 -> 2.97, 3.008 -> 3.65, 3.44 -> 3.97, 3.87 -> 4.16, 4.30 -> 4.88, 5.16 -> 5.8, 6.9 -> 7.2:
+    //     rounds_eff(x) = 1.03 floor(x) + (0.65 + 0.4 frac(x) if frac(x) > 0)
+    // and the chunk count that minimises rounds_eff x (zc + 2 K + 1) wins (chunks of at least 8 K planes while the depth
+    // allows).  The first model (whole rounds, a penalty for few of them) chose 9 chunks at 512^3 where 2 are 3 % faster,
+    // and on grids of 64 .. 256 planes -- the z-slabs of a multi-GPU run -- chunkings that were 6 - 13 % off the best.
     if (p.fused_z_chunk > 0) {
         a.zc = std::min(p.fused_z_chunk, end - begin);
     } else {
@@ -435,8 +440,10 @@ hipError_t launch_lanes_t(const Plan &p, const double *in, double *out, int begi
         long best_c = 1;
         for (long c = 1; c <= std::max(1L, depth / (8 * K)); ++c) {
             const long zc = (depth + c - 1) / c, wgs = tiles * ((depth + zc - 1) / zc);
-            const long rounds = (wgs + slots - 1) / slots;
-            const double cost = (double) rounds * (double) (zc + 2 * K + 1) * (1.0 + 0.5 / (double) rounds);
+            const double x = (double) wgs / (double) slots;
+            const double whole = std::floor(x), part = x - whole;
+            const double rounds = 1.03 * whole + (part > 1e-9 ? 0.65 + 0.4 * part : 0.0);
+            const double cost = rounds * (double) (zc + 2 * K + 1);
             if (best == 0.0 || cost < best) {
                 best = cost;
                 best_c = c;

@@ -483,14 +483,16 @@ int lora_slab_create(lora_slab **out, const lora_slab_desc *d, const lora_slab_c
     s->h0 = halo0_of(nd);
     s->radius = radius_of(nd);
     s->dirichlet = d->boundary == LORA_BC_DIRICHLET;
-    // Boundary strips first is the default in 1D and 3D.  In 2D the whole slab goes in one launch unless LORA_SLAB_OVERLAP
-    // asks for the strips: the six-sweep kernel runs ONE round of workgroups sized to its region, and a chunk pays 41
-    // warm-up steps whatever its length, so two 32-row strips cost two third-length launches on a nearly empty chip
+    // Boundary strips first is the default in 1D only.  In 2D and 3D the whole slab goes in one launch unless
+    // LORA_SLAB_OVERLAP asks for the strips: the fused kernels run ONE round of workgroups sized to their region, and a
+    // chunk pays its warm-up steps (41 in 2D, 9 planes in 3D) whatever its length, so two 32-row strips cost two
+    // third-length launches on a nearly empty chip
     // (ring of one over RCCL, GStencils/s per rank, strips + deferred wait / whole slab + deferred wait / whole slab +
     // wait at once: 2048-row share 789 / 879 / 930, 4096 rows 973 / 1114 / 1131, 8192 rows 1234 / 1251 / 1288 at a
     // refresh every 4 launches -- tools/cslab_overlap.py, profiles/r03_cslab_schedule_sweep.jsonl).  The deferred wait
     // stays: it is what hides a real link behind the next launch's interior.
-    s->overlap = nd == 2 ? (d->flags & LORA_SLAB_OVERLAP) != 0 : !(d->flags & LORA_SLAB_NO_OVERLAP);
+    // (3D, same sweep: 64-plane star share 329-424 with the strips, 436-521 whole; 96-plane box share 627-640 / 661-687)
+    s->overlap = nd >= 2 ? (d->flags & LORA_SLAB_OVERLAP) != 0 : !(d->flags & LORA_SLAB_NO_OVERLAP);
     s->defer_wait = !(d->flags & LORA_SLAB_NO_DEFER);
     if (comm) {
         s->comm = *comm;
@@ -551,10 +553,10 @@ int lora_slab_create(lora_slab **out, const lora_slab_desc *d, const lora_slab_c
         if (nd == 3 && apps == 3) apps = 2;
         // (2D slabs keep the plan's six per launch: ring-of-one shares of star2d1r 16384^2 at 8 GPUs, GStencils/s per rank,
         // six (workgroup-row kernel) / four (the same) / four (row-streaming): 847 / 825 / 703 -- tools/slab_shares.py)
-        // 3D: the register-resident kernel wants z-chunks of 32 planes and more; on slabs thinner than ~96 planes the
-        // two-application kernels are faster (star3d1r 512^3 shares, four / two per launch: 128 planes 489 / 431, 64 planes
-        // 253 / 321)
-        if (nd == 3 && apps == 4 && splitting && thinnest < 96 && !(d->options && std::strstr(d->options, "steps_per_launch="))) apps = 2;
+        // 3D slabs keep the plan's four per launch whatever their thickness: second form of the register-resident kernel +
+        // its chunk-length model + whole-slab launches, ring of one over RCCL, per rank, four / two per launch: 64-plane
+        // share of star3d1r 512^3 479-521 / 357-380, 128 planes 635-650 / 430-470; 96-plane share of box3d1r 768^3
+        // 661-687 / 434-448 (tools/cslab_3d_k.py, profiles/r03_cslab_3d_k.jsonl; the first form lost below 96 planes)
         while (apps > 1 && splitting && thinnest < s->radius * apps) apps = (nd >= 2 && apps >= 4) ? apps - 2 : 1;
     }
     s->apps = apps;

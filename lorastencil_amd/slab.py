@@ -146,12 +146,10 @@ class HipStepper:
             self.plan.set_option(k, int(v))
         if boundary == "dirichlet":
             self.plan.set_boundary(boundary)  # fused launches: intermediate halo cells keep the source's values
-        if (len(layout.local_dims) == 3 and self.plan.get_option("steps_per_launch") == 4 and layout.ghost > 0
-                and layout.own < 96 and "steps_per_launch" not in (options or {})):
-            # the register-resident 3D kernel wants z-chunks of 32 planes and more: on slabs thinner than ~96 planes the
-            # two-application kernels are faster (ring-of-one shares of star3d1r 512^3, GStencils/s per rank, four / two per
-            # launch: 128 planes 489 / 431, 64 planes 253 / 321; tools/slab_shares.py)
-            self.plan.set_option("steps_per_launch", 2)
+        # (3D slabs keep the plan's four sweeps per launch whatever their thickness: with the second form of the
+        # register-resident kernel, its chunk-length model and whole-slab launches a 64-plane share of star3d1r 512^3 runs
+        # 479-521 GStencils/s per rank with four per launch against 357-380 with two -- tools/cslab_3d_k.py; the first form
+        # lost to the two-sweep kernels below 96 planes)
         if boundary == "periodic":
             self.plan.set_option("steps_per_launch", 1)  # a fused launch would need the wrap of its inner levels
         elif len(layout.local_dims) == 3 and self.plan.get_option("steps_per_launch") == 3:
@@ -266,9 +264,10 @@ class SlabDriver:
             raise ValueError("slabs are thinner than the stencil radius")
         self.layout = layout
         self.radius = radius
-        # boundary strips first: the default in 1D / 3D; in 2D the whole slab goes in one launch (csrc/slab.cpp: a 32-row
-        # strip costs a third of a whole-slab launch of the six-sweep kernel) and only the deferred wait hides the link
-        self.overlap = (nd != 2) if overlap is None else bool(overlap)
+        # boundary strips first: the default in 1D only; in 2D and 3D the whole slab goes in one launch (csrc/slab.cpp: the
+        # fused kernels run ONE round of workgroups sized to their region, a thin strip costs a third of a whole-slab
+        # launch) and only the deferred wait hides the link
+        self.overlap = (nd == 1) if overlap is None else bool(overlap)
         self.local_padded_shape = ops.padded_shape(sid, layout.local_dims)
         self.buf = [torch.zeros(self.local_padded_shape, dtype=self.torch_dtype, device=self.device) for _ in range(2)]
         if boundary_rows is None:

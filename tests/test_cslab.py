@@ -59,9 +59,10 @@ def test_slab_descriptor_validation(L):
     ("box2d3r", (300, 130), 3, 6, 3, 0, None),
     ("star2d3r", (256, 200), 2, 9, 1, 4, None),      # single sweeps only
     ("star3d1r", (24, 20, 64), 3, 7, 2, 0, None),
+    ("star3d1r", (24, 20, 64), 3, 9, 1, 16, None),   # boundary planes first (3D slabs go whole by default too)
     ("box3d1r", (30, 16, 64), 2, 8, 0, 0, None),
     ("star3d1r", (60, 40, 130), 3, 11, 1, 0, {"steps_per_launch": 4}),  # the register-resident kernel in z-slabs: 4 + 4 + 2 + 1
-    ("box3d1r", (64, 30, 250), 4, 14, 2, 0, {"steps_per_launch": 4}),
+    ("box3d1r", (64, 30, 250), 4, 14, 2, 16, {"steps_per_launch": 4}),
     ("1d1r", (30000,), 3, 27, 2, 0, None),           # eight applications per launch + single sweeps
 ])
 def test_loopback_slabs_equal_single_gpu(L, shape, dims, nranks, times, every, flags, opts):
