@@ -360,11 +360,13 @@ void plan_refresh(Plan &p) {
         bool lanes = false;
         if (lanes_taps && p.lanes3 != 0 && p.steps_per_launch_req != 1 && p.steps_per_launch_req != 2 &&
             p.steps_per_launch_req != 3)
-            // (GStencils/s per launch, plane / tile kernels against this one, tools/lanes3_check.py: star 256^3 508 / 586,
-            // 384^3 531 / 700, 512^3 597 / 795, 768^3 706 / 904; box 256^3 453 / 423, 512^3 581 / 696, 768^3 680 / 818; odd
-            // innermost extent 512 x 512 x 511: 126 (one thread per point) / 782)
+            // (GStencils/s per launch, tile kernels (two per launch) against this one, tools/cube3d_check.py with the kernel's
+            // second form: star 192^3 491 / 347, 224^3 498 / 552, 256^3 554 / 678, 320^3 507 / 881, 384^3 610 / 944; box
+            // 224^3 504 / 441, 256^3 494 / 558, 320^3 512 / 765, 384^3 607 / 846; 256 x 512 x 128 444 / 532 and 414 / 442; odd
+            // innermost extent 512 x 512 x 511: 126 (one thread per point) / 892.  Below ~10 M points there are too few
+            // tiles x chunks for the one workgroup per CU this kernel runs.)
             lanes = p.steps_per_launch_req == 4 || p.lanes3 == 1 ||
-                    npts >= (p.generic ? 1.0e7 : (p.tapset == TAPS3D_STAR ? 1.6e7 : 5.0e7));
+                    npts >= (p.generic ? 1.0e7 : (p.tapset == TAPS3D_STAR ? 1.0e7 : 1.4e7));
         p.lanes3_active = lanes ? 1 : 0;
         if (lanes) {
             p.steps_per_launch = 4;
