@@ -405,7 +405,11 @@ hipError_t launch_wg_t(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
     } else {
         // ONE round: the most interior chunks for which every workgroup of the launch is resident at once
         const long slots = (long) per_cu_dev * cus;
-        const long min_rows = 4 * lag;  // small grids: a chunk recomputes 7 K - 1 rows, keep that under a quarter
+        // Small grids: filling the round matters more than the rows a chunk recomputes -- down to chunks of about 1.5 x
+        // the 7 K - 1 warm-up rows (star2d1r, six sweeps, GStencils/s at chunks of 64 / 100 / 128 / 164 / 256 rows: 4096^2
+        // 636 / 837 / 762 / 675 / 595, 2048^2 375 / 289 / 245 / 208 / 149, 1024 x 16384 685 / 875 / 775 / 816 / 595 --
+        // tools/wg_small.py; the first rule, four times the warm-up, left half the CUs idle on such grids)
+        const long min_rows = 3 * lag / 2;
         int best = fit(rows_total);
         for (long c = 1; c <= rows_total; ++c) {
             const int ri = fit((rows_total + c - 1) / c);
