@@ -272,6 +272,7 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
                             (unsigned) row1 < (unsigned) a.m ? hcol[e] : hall[e], 0, 0, 0);
 #else
                         (void) hsrc;
+                        (void) hb;
 #endif
                     }
                 }
