@@ -10,7 +10,8 @@ A "step" is one kernel application (one sweep of the whole grid): the reference'
 printout multiplies by 3 for this shape, 2d/gpu.cu:553; that figure is reported as `value_reference_convention`).
 Inputs are synthetic small integers (0..99, the range of the reference's rand()%100 fill) generated on the device
 and resident in HBM before the timed region.  For N > 1 the SAME 16384^2 grid is cut into N row slabs ("strong"
-scaling, as BASELINE.json quotes the metric) with one RCCL halo exchange per step overlapped with the interior.
+scaling, as BASELINE.json quotes the metric); ghost zones several launches deep are refreshed by one RCCL exchange every
+E launches, hidden behind the next launch's interior (lorastencil_amd/slab.py).
 
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts its own N ranks (a
 torch.distributed.run child, before this process touches the GPU) and relays rank 0's line.
@@ -394,7 +395,8 @@ def main():
     else:
         spl = drv.apps if drv.fused else 1
         nf, n2, ns = planned_launches(len(dims), K, spl, drv.fused)
-        # slab launches are issued from Python in pieces (boundary strips, interior): count applications, not pieces;
+        # slab launches can be issued from Python in pieces (interior first, ends after the deferred wait): count
+        # applications, not pieces;
         # the K-application launches' share of the timed region is taken as their share of the sweeps
         launches, apps = (nf, spl) if nf else (max(ns + n2, 1), 1)
         launch_s = ev_ms / 1e3 * (nf * spl / K if nf else 1.0) / max(launches, 1)
@@ -440,7 +442,9 @@ def main():
                 "workload": f"{shape} {'x'.join(map(str, dims))} {'bf16' if bf16 else 'fp64'}, {K} sweeps (lorastencil_{len(dims)}d {shape} "
                             f"{' '.join(map(str, dims))} {K})",
                 "parallelism": (f"row-slabs x{world}, ghost {drv.layout.ghost} rows refreshed every "
-                                f"{drv.exchange_every} launches ({drv.exchange_mode})") if world > 1 else "single GPU",
+                                f"{drv.exchange_every} launches ({drv.exchange_mode}, "
+                                f"{'boundary strips first' if drv.overlap else 'whole slab per launch'}, deferred wait)")
+                               if world > 1 else "single GPU",
                 "kernel": kernel,
                 "variant": {1: "direct", 2: "mfma"}.get(plan.get_option("variant"), "?"),
                 "normalised_taps": bool(normalised),
