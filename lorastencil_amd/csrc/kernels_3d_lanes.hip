@@ -49,10 +49,6 @@
 #ifndef LORA_L3_ABLATE
 #define LORA_L3_ABLATE 0
 #endif
-// probe only (tools/probes/lanes3_ablate.hip): touch ONE address of the plane LORA_L3_TLB steps ahead per wave and step
-#ifndef LORA_L3_TLB
-#define LORA_L3_TLB 0
-#endif
 
 namespace lora {
 
@@ -144,8 +140,6 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
 #pragma unroll
     for (int r = 0; r < 4; ++r) rowoff[r] = (long) min(max(Y0 + 4 * wv + r + 2, 0), a.m + 3) * a.ld;
     const int up = max(wv - 1, 0), dn = min(wv + 1, NW - 1);  // (the tile's outermost rows are never valid beyond level 0)
-    const int pc0 = min(max(X0 + 4, 0), a.n + 6);  // (probe: LORA_L3_TLB)
-    const unsigned tlb_pad = (unsigned) (size_t) (__attribute__((address_space(3))) void *) &edge_rows[wv >> 2][0][0][(wv & 3) * 32];
     // (An L2 prefetch of the planes two or three steps ahead -- one 4-byte LDS-DMA per lane and step touching the wave's
     // 64-byte pieces, landing in an LDS row nobody reads -- made the launch 5-12 % SLOWER, with and without the arithmetic:
     // the launch is bound by the bytes this access pattern moves, 2.7 GB at ~4.9 TB/s, not by the latency of its loads.
@@ -203,7 +197,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
         // used -- right here, and with stores outstanding beside them it waits for vmcnt(0), which is what this step wants
         // anyway -- and it never copies or spills a register whose load is still in flight (loads issued and waited for in
         // separate asm statements gave wrong planes at 256 VGPRs).
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LORA_L3_TLB > 0 ? 2 : 0) : "memory");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         {
             const int o = p - 2 * K - 1;  // the output plane completed in the previous step: level K's slot of phase P - 1
             const bool live = o >= 0 && o < zc;
@@ -227,21 +221,6 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
             for (int r = 0; r < 4; ++r) nxt[P1][r] = nxt[P][r] + (d2){1e-9, 1e-9};
         } else {
             load_plane(p + 1, nxt[P1]);
-        }
-        if constexpr (LORA_L3_TLB > 0) {
-            const double *tsrc = a.in + (long) min(max(k0 - K + p + 1 + LORA_L3_TLB, 0), a.h + 1) * a.plane + rowoff[0] + pc0;
-            double *tdst = a.out + (long) min(max(k0 + p - 2 * K + LORA_L3_TLB, 0), a.h + 1) * a.plane + rowoff[0] + pc0;
-            unsigned saved_m0;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\t"
-                "s_mov_b32 m0, %1\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dword %2, off\n\t"
-                "global_load_lds_dword %3, off\n\t"
-                "s_mov_b32 m0, %0"
-                : "=&s"(saved_m0)
-                : "s"(tlb_pad), "v"(tsrc), "v"(tdst)
-                : "memory");
         }
         if (EDGE && K > 2) {
             // The value a level-2 cell outside the interior is forced to is the source buffer's own value there (while fused
