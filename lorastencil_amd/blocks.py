@@ -158,8 +158,9 @@ class Block:
             self.stepper.step(src, dst)
         self.cur = dst_i
 
-    def store_own(self, out: np.ndarray) -> None:
-        """own cells (and the global-edge pads this block holds) of the current buffer into the global padded array"""
+    def own_piece(self):
+        """(row, column, array): own cells (and the global-edge pads this block holds) of the current buffer and where they
+        go in the global padded array"""
         lay = self.lay
         t = self.buf[self.cur].cpu().numpy()
         (m, n), (py, px), (iy, ix) = lay.global_dims, lay.grid, lay.coords
@@ -169,7 +170,7 @@ class Block:
         lc1 = lay.col0 + lay.own[1] + (HALO if ix == px - 1 else 0)
         gr0 = lay.r0 + HALO - (HALO if iy == 0 else 0)
         gc0 = lay.c0 + HALO - (HALO if ix == 0 else 0)
-        out[gr0:gr0 + (lr1 - lr0), gc0:gc0 + (lc1 - lc0)] = t[lr0:lr1, lc0:lc1]
+        return gr0, gc0, np.ascontiguousarray(t[lr0:lr1, lc0:lc1])
 
 
 class BlockSet:
@@ -267,11 +268,14 @@ class BlockSet:
         north = (iy - 1) * px + ix if iy > 0 else None
         south = (iy + 1) * px + ix if iy + 1 < py else None
         sends, recvs, ops_l = {}, {}, []
+        if not hasattr(self, "_pack"):  # contiguous strips for the column ghost zones, made once
+            self._pack = {side: (torch.empty((rows, g), dtype=t.dtype, device=t.device),
+                                 torch.empty((rows, g), dtype=t.dtype, device=t.device))
+                          for side, peer in (("w", west), ("e", east)) if peer is not None}
         for side, peer, src_col in (("w", west, lay.col0), ("e", east, lay.col0 + lay.own[1] - g)):
             if peer is None:
                 continue
-            sends[side] = torch.empty((rows, g), dtype=t.dtype, device=t.device)
-            recvs[side] = torch.empty((rows, g), dtype=t.dtype, device=t.device)
+            sends[side], recvs[side] = self._pack[side]
             b.stepper.copy_block(sends[side], 0, g, t, lay.row0 * ld + src_col, ld, rows, g)  # pack
         if t.is_cuda and dist.get_backend(self.group) != "nccl" and sends:
             torch.cuda.current_stream(t.device).synchronize()
@@ -326,19 +330,17 @@ class BlockSet:
 
     def store(self, out: np.ndarray | None = None, dst_rank: int = 0):
         """the global padded result (own cells of every block, global-edge pads from the rim blocks); distributed: on
-        ``dst_rank`` only (None elsewhere)"""
+        ``dst_rank`` only (None elsewhere) -- every rank contributes the piece it owns, not a global-sized array"""
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
-        full = np.zeros((self.global_dims[0] + 2 * HALO, self.global_dims[1] + 2 * HALO))
-        for b in self.blocks.values():
-            b.store_own(full)
+        pieces = [b.own_piece() for b in self.blocks.values()]
         if self.distributed:
-            pieces = [None] * dist.get_world_size(self.group) if self.rank == dst_rank else None
-            dist.gather_object(full, pieces, dst=dst_rank, group=self.group)
+            gathered = [None] * dist.get_world_size(self.group) if self.rank == dst_rank else None
+            dist.gather_object(pieces, gathered, dst=dst_rank, group=self.group)
             if self.rank != dst_rank:
                 return None
-            full = np.sum(pieces, axis=0)  # every cell is written by exactly one block, zero elsewhere
-        if out is not None:
-            out[...] = full
-            return out
+            pieces = [p for rank_pieces in gathered for p in rank_pieces]
+        full = out if out is not None else np.zeros((self.global_dims[0] + 2 * HALO, self.global_dims[1] + 2 * HALO))
+        for r0, c0, a in pieces:
+            full[r0:r0 + a.shape[0], c0:c0 + a.shape[1]] = a
         return full
