@@ -18,6 +18,14 @@ namespace lora {
 typedef double d2 __attribute__((ext_vector_type(2)));
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// Cache policy of the fused kernels' output stores (the `aux` operand of raw_buffer_store: 2 = nt on gfx950).  A launch
+// never re-reads what it writes, and streamed lines leave the L2 / Infinity Cache to the rows and planes neighbouring
+// workgroups re-read: 1.5 - 3 % per launch (old / new library in one process, two alternations: star3d1r 512^3 four sweeps
+// 632, 624 -> 613, 613 us; box3d1r 768^3 2114, 2100 -> 2085, 2075; star2d1r 16384^2 six sweeps 1240, 1243 -> 1221, 1223;
+// profiles/r03_nt_stores_ab.txt; run-to-run noise on one box is about +-1.5 %, so this is a small effect at best.  The bf16
+// kernel's 8-byte stores got SLOWER with it, 567-574 -> 618-631 us, and keep the default policy).
+constexpr int kStoreNT = 2;
+
 // Which of the 49 taps a kernel instantiation evaluates (dy, dx in 0..6).
 template <int TAPSET>
 __host__ __device__ constexpr bool tap_on(int dy, int dx) {

@@ -235,7 +235,7 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
                     const bool live = row >= i0 && row < row_hi;
                     const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
                         out_strip + (size_t) (max(row, 0) + 4) * a.ld, 0, live ? row_bytes : 0u, 0x00020000);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, store_off, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), dst, store_off, 0, kStoreNT);
                 } else {
                     if (EDGE) {
                         // v = inside ? v : h as a bitwise blend under integer masks the compiler cannot see through: from a

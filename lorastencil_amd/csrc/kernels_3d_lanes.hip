@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
                 const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                     dst + rowoff[r], 0, (live && st_row[r]) ? (unsigned) a.n * 8u : 0u, 0x00020000);
                 const d2 ov = {acc[K - 1][P2][r][0], acc[K - 1][P2][r][1]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs, (LORA_L3_ABLATE & 2) ? 0x80000000u : st_off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, ov), rs, (LORA_L3_ABLATE & 2) ? 0x80000000u : st_off, 0, kStoreNT);
             }
         }
         double v0[4][2];  // the input plane of level 1
