@@ -113,6 +113,63 @@ def slab_layout(shape, global_dims: Sequence[int], world_size: int, rank: int, m
     return lay
 
 
+def slab_schedule(sid, global_dims, world_size, rank, ring, make_stepper, fused, exchange_every, all_agree=bool):
+    """Launch depth, ghost need and refresh interval of a slab decomposition, and this rank's layout and stepper.
+    Everything that fixes the exchange pattern comes from rank-independent data; `all_agree` ANDs a local verdict over
+    the ranks (identity for a single process).  Returns (layout, stepper, apps, need, every) or None when even single
+    sweeps do not fit the thinnest slab."""
+    nd = len(global_dims)
+    radius = slab_layout(sid, global_dims, world_size, rank, ring=ring).radius0
+    # thinnest slab of the decomposition bounds the ghost depth (neighbours supply ghost rows from own rows)
+    thinnest = min(slab_layout(sid, global_dims, world_size, r).own for r in range(world_size))
+    auto_every = exchange_every is None
+    split = world_size > 1 or ring
+    # Applications of a fused launch (lora_plan_stepk): fixed ONCE from rank-independent data -- a probe stepper on the
+    # GLOBAL dims, as csrc/slab.cpp does -- and then forced on every rank's local plan.  (A plan resolves its depth from
+    # its own grid size: a 3D fp64 plan takes four per launch from ~1e7 points and two below, and the ranks at the ends
+    # of the decomposition hold fewer planes than the ones in the middle.  Ranks that resolved different depths would
+    # disagree on ghost depth, message sizes and exchange cadence: star3d1r 208 x 384 x 384 on 4 ranks gave (2, 4) at
+    # the ends and (4, 8) in the middle.)
+    default_apps = 8 if nd == 1 else 2
+    probe_apps = 1
+    if fused:
+        whole = make_stepper(slab_layout(sid, global_dims, 1, 0))
+        if getattr(whole, "wants_fused", True) and (hasattr(whole, "stepk_region") or hasattr(whole, "step2_region")):
+            probe_apps = int(getattr(whole, "apps_per_launch", default_apps))
+        del whole
+    candidates = [probe_apps]
+    while candidates[-1] > 1:  # what a slab too thin for the probe's depth falls back to: csrc/slab.cpp's sequence
+        a = candidates[-1]
+        candidates.append(a - 2 if (nd >= 2 and a >= 4) else 1)
+    for apps in candidates:
+        need = radius * apps
+        if split and thinnest < need:
+            continue
+        if auto_every:
+            # refresh as rarely as keeps the redundant ghost sweeps (about (E - 1) x need rows per launch) within
+            # ~10 % of a slab: 8 launches for the 2D / 1D configurations, 4 for the thin 3D slabs of an 8-GPU run
+            # (ring of one over RCCL, 2048 x 16384 slab: E = 2 / 4 / 8 / 16 -> 492 / 535 / 553 / 534 GStencils/s)
+            exchange_every = 8
+            while exchange_every > 1 and (exchange_every - 1) * need > 0.1 * thinnest:
+                exchange_every //= 2
+        e = max(1, min(exchange_every, thinnest // need if split else exchange_every))
+        layout = slab_layout(sid, global_dims, world_size, rank, ghost=need * e, ring=ring)
+        stepper = make_stepper(layout)
+        agrees = True
+        if apps > 1:
+            if hasattr(stepper, "set_apps"):
+                stepper.set_apps(apps)  # the local plan takes the depth it is given, whatever its own size says
+            has = hasattr(stepper, "stepk_region") or hasattr(stepper, "step2_region")
+            agrees = bool(has and getattr(stepper, "wants_fused", True)
+                          and int(getattr(stepper, "apps_per_launch", default_apps)) == apps)
+        # every rank takes the same branch: one rank's local plan declining the depth (an odd innermost extent, a
+        # stepper without fused launches) moves ALL ranks on to the next candidate, never just that one
+        if not all_agree(agrees):
+            continue
+        return layout, stepper, apps, need, e
+    return None
+
+
 class _GatherWork:
     """Completion handle of the all-gather form of the ghost exchange: wait() also scatters the neighbours' strips."""
 
@@ -170,6 +227,11 @@ class HipStepper:
     @property
     def wants_fused(self) -> bool:
         return self.apps_per_launch > 1
+
+    def set_apps(self, apps: int) -> None:
+        """Force the launch depth the slab driver chose from the GLOBAL grid (every rank the same), whatever this rank's
+        local grid size would have resolved; apps_per_launch then says what the plan really does."""
+        self.plan.set_option("steps_per_launch", int(apps))
 
     def step_region(self, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
         self.plan.step_region(src.data_ptr(), dst.data_ptr(), begin, end, stream=self.stream)
@@ -229,37 +291,12 @@ class SlabDriver:
         self._make_stepper = stepper_factory or (
             lambda lay: HipStepper(lay, params=params, weights=weights, dtype=self.dtype, boundary=boundary,
                                    options=options, variant=variant))
-        # thinnest slab of the decomposition bounds the ghost depth (neighbours supply ghost rows from own rows)
-        thinnest = min(slab_layout(sid, global_dims, self.world_size, r).own for r in range(self.world_size))
-        auto_every = exchange_every is None
+        sched = slab_schedule(sid, global_dims, self.world_size, self.rank, self._ring, self._make_stepper, fused,
+                              exchange_every, self._all_agree)
         layout = None
-        # applications of a fused launch (lora_plan_stepk): 8 in 1D, 4 (row-streaming kernel) or 2 in 2D, 2 in 3D -- the
-        # first candidate the stepper agrees with decides the ghost depth
-        default_apps = 8 if nd == 1 else 2
-        candidates = {1: [8], 2: [6, 4, 2], 3: [4, 2]}[nd]
-        for apps in (candidates + [1] if fused else [1]):
-            need = radius * apps
-            split = self.world_size > 1 or self._ring
-            if auto_every:
-                # refresh as rarely as keeps the redundant ghost sweeps (about (E - 1) x need rows per launch) within
-                # ~10 % of a slab: 8 launches for the 2D / 1D configurations, 4 for the thin 3D slabs of an 8-GPU run
-                # (ring of one over RCCL, 2048 x 16384 slab: E = 2 / 4 / 8 / 16 -> 492 / 535 / 553 / 534 GStencils/s)
-                exchange_every = 8
-                while exchange_every > 1 and (exchange_every - 1) * need > 0.1 * thinnest:
-                    exchange_every //= 2
-            e = max(1, min(exchange_every, thinnest // need if split else exchange_every))
-            if split and thinnest < need:
-                continue
-            layout = slab_layout(sid, global_dims, self.world_size, self.rank, ghost=need * e, ring=self._ring)
-            stepper = self._make_stepper(layout)
-            if apps > 1:
-                has = hasattr(stepper, "stepk_region") or hasattr(stepper, "step2_region")
-                if not (has and getattr(stepper, "wants_fused", True)
-                        and getattr(stepper, "apps_per_launch", default_apps) == apps):
-                    continue  # the stepper declines fusion (or fuses a different number of applications)
-            self.fused, self.apps, self.need, self.exchange_every = apps > 1, apps, need, e
-            self.stepper = stepper
-            break
+        if sched is not None:
+            layout, self.stepper, self.apps, self.need, self.exchange_every = sched
+            self.fused = self.apps > 1
         if layout is None or not hasattr(self, "stepper"):
             raise ValueError("slabs are thinner than the stencil radius")
         self.layout = layout
@@ -284,6 +321,16 @@ class SlabDriver:
         self.cur = 0  # physical buffer holding the current time level
         self.valid = layout.ghost  # ghost rows per side that hold the current time level
         self.ring = ["input", "zero"]  # what the halo ring of each physical buffer holds (fused-launch bookkeeping)
+
+    def _all_agree(self, ok: bool) -> bool:
+        """AND of a local verdict over the ranks of the group (a collective: every rank calls it at the same point of
+        the constructor), so that no rank raises or moves on alone while the others enter an exchange and hang."""
+        if not (dist.is_initialized() and self.world_size > 1):
+            return bool(ok)
+        dev = self.device if dist.get_backend(self.group) == "nccl" else torch.device("cpu")
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(int(t.item()))
 
     def _on_stream(self):
         """Everything the driver enqueues -- sweeps, halo-ring copies, the P2P batch and its waits -- must be ordered on

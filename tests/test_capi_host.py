@@ -273,3 +273,32 @@ def test_kernel_signature_names_every_selecting_option(L):
     assert L.Plan("1d1r", (4096,)).kernel_signature == "stencil1d_fusedk_kernel[k=8]"
     with pytest.raises(L.LoraError):
         L.Plan("1d1r", (2**31 - 8,))  # padded extent n + 8 would overflow the kernels' 32-bit indices
+
+
+@pytest.mark.parametrize("shape,dims,world", [
+    ("star3d1r", (208, 384, 384), 4),   # end ranks resolved (2, 4), middle ranks (4, 8)
+    ("star3d1r", (160, 384, 384), 3),
+    ("star3d1r", (496, 256, 256), 4),
+    ("box3d1r", (300, 384, 384), 4),
+    ("star3d1r", (512, 512, 512), 8),
+    ("star2d1r", (16384, 16384), 8),
+    ("box2d3r", (8192, 8191), 4),       # odd innermost extent
+    ("1d1r", (1 << 20,), 8),
+])
+def test_slab_schedule_is_the_same_on_every_rank(L, shape, dims, world):
+    """The launch depth, ghost need and refresh interval of a slab run come from the GLOBAL grid and are forced on every
+    rank's local plan (lorastencil_amd/slab.py: slab_schedule): replay the selection for each rank of decompositions
+    whose local grids straddle the plans' size crossovers and require identical answers.  Host logic only."""
+    from lorastencil_amd import ops, slab
+
+    sid = ops.shape_id(shape)
+    make = lambda lay: slab.HipStepper(lay)
+    seen = set()
+    for rank in range(world):
+        sched = slab.slab_schedule(sid, dims, world, rank, False, make, True, None)
+        assert sched is not None
+        layout, stepper, apps, need, every = sched
+        assert stepper.apps_per_launch == apps, (rank, stepper.apps_per_launch, apps)
+        assert layout.ghost == need * every
+        seen.add((apps, need, every, layout.ghost))
+    assert len(seen) == 1, seen
