@@ -403,12 +403,10 @@ def main():
     bytes_per_launch = local_points * 2.0 * esize          # compulsory: one read + one write of the grid
     achieved = bytes_per_launch / launch_s / 1e9
     one_sweep_equiv = achieved * apps                       # 2 x sizeof(T) per point per APPLICATION
-    # the other roof: algorithmic flops (direct form) against the fp64 FMA peak.  A launch that fuses K applications does
-    # K x the arithmetic on the same bytes, so deep fusion moves the kernel from the HBM roof towards this one; the
-    # line reports both and names the one the kernel sits closer to as `bound`.
-    flops_per_launch = float(FLOPS_PER_POINT.get(shape, 0)) * local_points * apps
-    tflops = flops_per_launch / launch_s / 1e12
-    hbm_frac, flop_frac = achieved / HBM_PEAK_GBS, (tflops / FP64_PEAK_TFLOPS if not bf16 else 0.0)
+    # the other roof is arithmetic; everything about it is derived below from the counters of this kernel's profile
+    flops_per_launch = float(FLOPS_PER_POINT.get(shape, 0)) * local_points * apps   # direct form: "useful", NOT executed
+    useful_tflops = flops_per_launch / launch_s / 1e12
+    hbm_frac = achieved / HBM_PEAK_GBS
     traffic, pmc = None, {}
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     tkey = f"{shape}:{'x'.join(map(str, dims))}:{world}:{signature}"
@@ -424,6 +422,48 @@ def main():
         elif entry is not None:
             traffic, pmc = entry, {}
 
+    # ---- what the silicon did (VERDICT r03 #2 / ADVICE r03) ------------------------------------------------------------
+    # The kernels evaluate a low-rank FORM of the stencil (nested profiles, pyramid terms, separable passes): far fewer
+    # operations than the direct form's 2 nnz - 1 flops per point.  The arithmetic roof is therefore priced on EXECUTED
+    # instructions -- SQ_INSTS_VALU_{FMA,ADD,MUL}_F64 per launch from the kernel's own PMC profile (64 lanes x 2 flops per
+    # FMA, x 1 per add / multiply), divided by THIS run's launch duration -- against the fp64 peak (spec, 2.4 GHz) and
+    # against the peak at the clock the chip held under the kernel.  The direct-form figure stays, labelled `useful`.
+    kinds = pmc.get("valu_insts_by_kind") or {}
+    p32 = bf16
+    sfx = "f32" if p32 else "f64"
+    executed = None
+    if kinds.get(f"fma_{sfx}") is not None:
+        n_fma, n_add, n_mul = kinds.get(f"fma_{sfx}", 0), kinds.get(f"add_{sfx}", 0), kinds.get(f"mul_{sfx}", 0)
+        ex_flops = 64.0 * (2.0 * n_fma + n_add + n_mul)
+        clock = pmc.get("clock_ghz")
+        # fp64: 16 lanes x 2 flops per SIMD and cycle (v_fma_f64 issues over 4 cycles); fp32: the same lanes, two values each
+        # when packed (v_pk_fma_f32) -- the 157.3 TFLOP/s figure -- so the fp32 roof is priced on the packed rate
+        peak_spec = FP64_PEAK_TFLOPS * (2.0 if p32 else 1.0)
+        peak_clk = (clock * 256 * 4 * 16 * 2 * (2.0 if p32 else 1.0) / 1e3) if clock else None
+        executed = {
+            "tflops": round(ex_flops / launch_s / 1e12, 2),
+            "frac": round(ex_flops / launch_s / 1e12 / peak_spec, 4),
+            "peak_at_clock_tflops": round(peak_clk, 1) if peak_clk else None,
+            "frac_at_clock": round(ex_flops / launch_s / 1e12 / peak_clk, 4) if peak_clk else None,
+            "ops_per_point": round(64.0 * (n_fma + n_add + n_mul) / (local_points * apps), 2),
+            "insts_per_launch": {"fma": n_fma, "add": n_add, "mul": n_mul},
+        }
+    traffic_gbs = traffic / launch_s / 1e9 if traffic else None
+    # which resource the kernel uses most of what it can get: the vector pipe's busy share, the LDS array's, and the HBM
+    # stream (measured bytes when there are any) against a plain copy of the same grid on this box in this process
+    util = {"hbm": ((traffic_gbs or achieved) / copy_gbs) if copy_gbs else hbm_frac,
+            "valu": pmc.get("valu_busy"), "lds": pmc.get("lds_active")}
+    limiter = max((k for k in util if util[k] is not None), key=lambda k: util[k])
+    arith_name = "fp32_valu" if p32 else "fp64_valu"
+    if executed is not None:
+        arith_frac, arith_achieved = executed["frac"], executed["tflops"]
+        arith_peak = FP64_PEAK_TFLOPS * (2.0 if p32 else 1.0)
+    else:  # no counters for this instantiation: the direct-form figure, capped by what the pipe can do
+        arith_frac, arith_achieved, arith_peak = (0.0 if p32 else min(useful_tflops / FP64_PEAK_TFLOPS, 1.0)), useful_tflops, FP64_PEAK_TFLOPS
+    if util["valu"] is not None:
+        bound_hbm = util["hbm"] >= util["valu"]
+    else:
+        bound_hbm = hbm_frac >= arith_frac
     if rank == 0:
         res = {
             "metric": "GStencils/s",
@@ -453,21 +493,31 @@ def main():
             },
             "value_reference_convention": round(value * L.ops.gstencil_factor(shape), 3),
             "roofline": {
-                # "fp64_valu": the fp64 FMA rate of the vector pipe (78.6 TFLOP/s).  It is also the MFMA f64 rate, and not a
-                # second pipe: v_mfma_f64 and v_fma_f64 share one datapath on gfx950 (profiles/r03_fp64_coissue_probe.txt)
-                "bound": "hbm" if hbm_frac >= flop_frac else "fp64_valu",
+                # `bound`: the resource this kernel uses the larger share of -- the HBM stream (measured bytes per launch
+                # against a plain copy on this box) or the vector pipe (SQ_ACTIVE_INST_VALU busy share) -- from the kernel's
+                # PMC profile; without one, the nearer roof.  `achieved` / `peak` / `frac` are that roof's: hbm = COMPULSORY
+                # bytes per launch / launch duration against 8 TB/s; fp64_valu = EXECUTED flops per launch / the same duration
+                # against the fp64 FMA peak (also the MFMA f64 rate: one shared datapath, profiles/r03_fp64_coissue_probe.txt)
+                "bound": "hbm" if bound_hbm else arith_name,
+                "limiter": limiter,
+                "utilisation": {k: (round(v, 3) if v is not None else None) for k, v in util.items()},
                 "kernel": signature,
-                "achieved": round(achieved, 1) if hbm_frac >= flop_frac else round(tflops, 2),
-                "peak": HBM_PEAK_GBS if hbm_frac >= flop_frac else FP64_PEAK_TFLOPS,
-                "unit": "GB/s" if hbm_frac >= flop_frac else "TFLOP/s",
-                "frac": round(max(hbm_frac, flop_frac), 4),
+                "achieved": round(achieved, 1) if bound_hbm else round(arith_achieved, 2),
+                "peak": HBM_PEAK_GBS if bound_hbm else arith_peak,
+                "unit": "GB/s" if bound_hbm else "TFLOP/s",
+                "frac": round(hbm_frac if bound_hbm else arith_frac, 4),
                 "hbm": {"achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_frac, 4)},
-                "fp64": {"achieved": round(tflops, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(flop_frac, 4), "flops_per_point_algorithmic": FLOPS_PER_POINT.get(shape),
-                         "note": "fp64 matrix peak = vector peak on gfx950 (one shared datapath); the kernel issues v_fma_f64"},
+                ("fp32" if p32 else "fp64"): {
+                    "executed": executed,
+                    "useful_direct_form_tflops": round(useful_tflops, 2),
+                    "useful_direct_form_frac": round(useful_tflops / FP64_PEAK_TFLOPS, 4) if not p32 else None,
+                    "flops_per_point_direct_form": FLOPS_PER_POINT.get(shape),
+                    "peak": FP64_PEAK_TFLOPS * (2.0 if p32 else 1.0), "unit": "TFLOP/s",
+                    "note": "executed = SQ_INSTS_VALU_{FMA,ADD,MUL} of this kernel's profile x 64 lanes (FMA = 2 flops) / this run's "
+                            "launch duration; the direct-form figure counts flops the low-rank evaluation never performs"},
                 "traffic": traffic,
                 # the same launch duration applied to the MEASURED bytes
-                "traffic_gbs": round(traffic / launch_s / 1e9, 1) if traffic else None,
+                "traffic_gbs": round(traffic_gbs, 1) if traffic_gbs else None,
                 "traffic_key": tkey,
                 # fraction of SIMD issue cycles spent on vector-ALU / matrix instructions, from the SQ counter passes of
                 # the profile `traffic` comes from (null when that profile has none): the utilisation of the pipe the
@@ -478,6 +528,8 @@ def main():
                 # of the vector pipe's issue slots, the share that issued fp64 arithmetic; and the shader clock the chip
                 # held under this kernel (GRBM_GUI_ACTIVE / 8 / duration) -- both from the same profile
                 "valu_issue_frac": pmc.get("fp64_issue_frac"),
+                "lds_active": pmc.get("lds_active"),
+                "wait_inst_frac": pmc.get("wait_inst_frac"),
                 "clock_ghz": pmc.get("clock_ghz"),
                 "pmc_source": pmc.get("source"),
                 # the chip's clocks ramp up over the first ~50 ms of load and settle after ~100 ms: a shorter

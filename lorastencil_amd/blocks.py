@@ -44,6 +44,8 @@ RADIUS = 3  # every 2D shape of the reference has radius 3
 def _split(n: int, parts: int, k: int) -> tuple[int, int]:
     """[begin, end) of part k of n cells in `parts` nearly equal parts, every boundary at an even index (16-byte rows)."""
     base = (n // parts) & ~1
+    if base < 2:
+        raise ValueError(f"cannot cut {n} cells into {parts} blocks of at least two")
     b = k * base
     e = n if k == parts - 1 else (k + 1) * base
     return b, e
@@ -93,6 +95,10 @@ class HipBlockStepper:
     @property
     def apps_per_launch(self) -> int:
         return self.plan.get_option("steps_per_launch")
+
+    def set_apps(self, apps: int) -> None:
+        """the launch depth the driver chose for EVERY block (from the global grid), whatever this block's size resolves"""
+        self.plan.set_option("steps_per_launch", int(apps))
 
     def step(self, src, dst):
         self.plan.step(src.data_ptr(), dst.data_ptr(), stream=self.stream)
@@ -190,9 +196,11 @@ class BlockSet:
                 raise ValueError("one rank per block: world size must be Py x Px")
             self.rank = dist.get_rank(group)
         make = stepper_factory or (lambda lay: HipBlockStepper(shape, lay, weights=weights, options=options))
-        # applications per launch as the engine resolves them on a block-sized grid, then the ghost depth, then the real thing
-        probe = make(BlockLayout(self.global_dims, self.grid, (0, 0), 0))
+        # applications per launch as the engine resolves them on the GLOBAL grid (rank-independent, like the slab drivers),
+        # then the ghost depth, then the real thing -- with that depth forced on every block's plan
+        probe = make(BlockLayout(self.global_dims, (1, 1), (0, 0), 0))
         self.apps = int(probe.apps_per_launch)
+        del probe
         self.need = RADIUS * self.apps
         thinnest = min(min(BlockLayout(self.global_dims, self.grid, (iy, ix), 0).own)
                        for iy in range(self.grid[0]) for ix in range(self.grid[1]))
@@ -202,15 +210,24 @@ class BlockSet:
         self.exchange_every = e
         self.ghost = self.need * e
         self.blocks = {}
+        agree = True
         for iy in range(self.grid[0]):
             for ix in range(self.grid[1]):
                 if self.distributed and iy * self.grid[1] + ix != self.rank:
                     continue
                 lay = BlockLayout(self.global_dims, self.grid, (iy, ix), self.ghost)
                 st = make(lay)
-                if int(st.apps_per_launch) != self.apps:
-                    raise ValueError("a block resolves another launch depth than the probe")
+                if hasattr(st, "set_apps"):
+                    st.set_apps(self.apps)
+                agree = agree and int(st.apps_per_launch) == self.apps
                 self.blocks[(iy, ix)] = Block(shape, lay, st, self.device)
+        if self.distributed:  # every rank raises together, or none does (a lone raise leaves the others in an exchange)
+            dev = self.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+            verdict = torch.tensor([1 if agree else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(verdict, op=dist.ReduceOp.MIN, group=group)
+            agree = bool(int(verdict.item()))
+        if not agree:
+            raise ValueError("a block's plan cannot run the launch depth chosen for the grid")
         self.valid = self.ghost
         self.steps_done = 0
         self.exchanges = 0

@@ -379,7 +379,21 @@ void plan_refresh(Plan &p) {
         }
         if (p.sep64_valid && !lanes)
             for (int k = 0; k < 9; ++k) p.sep64[k] = cba64[k];
-        p.kernel_name = (p.dtype == LORA_BF16)
+        // bf16: FOUR applications per launch with the levels in registers (kernels_3d_bf16_lanes.hip): exactly separable box
+        // taps on the vector pipe, reference boundary.  A tile is 56 x 120 output points on one 1024-thread workgroup per
+        // CU, so the launch wants ~256 tiles x long chunks: by grid size (lanes3 = -1), never (0), always (1);
+        // steps_per_launch = 4 asks for it by itself.
+        bool blanes = false;
+        if (p.dtype == LORA_BF16 && p.tapset == TAPS3D_SEP && p.boundary == LORA_BC_REFERENCE &&
+            p.variant != LORA_VARIANT_MFMA && p.lanes3 != 0 && !p.generic &&
+            (p.steps_per_launch_req == 0 || p.steps_per_launch_req == 4))
+            blanes = (p.steps_per_launch_req == 4 || p.lanes3 == 1 || npts >= 2.0e7) && prepare_3d_bf16_lanes(p);
+        if (blanes) {
+            p.lanes3_active = 1;
+            p.steps_per_launch = 4;
+        }
+        p.kernel_name = blanes ? kernel_name_3d_bf16_lanes(p)
+                        : (p.dtype == LORA_BF16)
                             ? (p.steps_per_launch == 2 ? (p.variant == LORA_VARIANT_MFMA ? kernel_name_3d_bf16_mfma2(p)
                                                                                           : kernel_name_3d_bf16_fused2(p))
                                                        : kernel_name_3d_bf16(p))
@@ -716,7 +730,7 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "steps_per_launch")) {
         const bool three = value == 3 && p.ndim == 3 && p.dtype != LORA_BF16;  // 3D fp64 plane-streaming kernel
         const bool six = value == 6 && p.ndim == 2;                             // 2D workgroup-row kernel
-        const bool four3 = value == 4 && p.ndim == 3 && p.dtype != LORA_BF16;  // 3D fp64 register-resident kernel
+        const bool four3 = value == 4 && p.ndim == 3;  // 3D register-resident kernels (fp64: star / separable box; bf16: separable box)
         if (value < 0 || value > 32 || ((value & (value - 1)) && !three && !six)) return LORA_EINVAL;  // 0 (auto), 1, 2, 4, 8, 16, 32
         if (value > 8 && p.ndim != 1) return LORA_EUNSUPPORTED;  // 16 and 32 exist in 1D only
         const bool fusable = (p.ndim == 2 && p.variant == LORA_VARIANT_DIRECT && (!p.generic || p.stream2)) ||
@@ -833,6 +847,8 @@ const char *lora_plan_kernel_signature(const lora_plan *plan) {
     else if (k == "stencil3d_lanes_kernel")
         std::snprintf(buf, sizeof buf, "taps=%d,k=%d,fzc=%d,bc=%d", p.sep64_valid ? 2 : p.tapset, p.steps_per_launch, p.fused_z_chunk,
                       p.boundary);
+    else if (k == "stencil3d_bf16_lanes_kernel")
+        std::snprintf(buf, sizeof buf, "taps=%d,k=%d,fzc=%d,bc=%d", p.tapset, p.steps_per_launch, p.fused_z_chunk, p.boundary);
     else if (k == "stencil3d_planes_kernel")
 {
         const int K = p.steps_per_launch, pipe = (K == 2 || p.stream3_pipe) ? 1 : 0;
@@ -876,8 +892,10 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
     if (p.ndim == 3 && p.lanes3_active) {  // the two-application tail of a four-application plan (also: odd innermost extents)
         if (int rc = lora::check_buffers(d_in, d_out)) return rc;
         if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
-        const hipError_t e = lora::launch_3d_lanes(p, 2, static_cast<const double *>(d_in), static_cast<double *>(d_out), begin,
-                                                   end, static_cast<hipStream_t>(stream));
+        const hipError_t e = p.dtype == LORA_BF16
+                                 ? lora::launch_3d_bf16_lanes(p, 2, d_in, d_out, begin, end, static_cast<hipStream_t>(stream))
+                                 : lora::launch_3d_lanes(p, 2, static_cast<const double *>(d_in), static_cast<double *>(d_out), begin,
+                                                         end, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) {
             lora::set_last_error("fused register-resident 3D kernel launch", e);
             return LORA_EHIP;
@@ -975,8 +993,10 @@ int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int b
     if (p.ndim == 3 && p.lanes3_active && (p.steps_per_launch == 4 || p.steps_per_launch == 2)) {
         if (int rc = lora::check_buffers(d_in, d_out)) return rc;
         if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
-        const hipError_t e = lora::launch_3d_lanes(p, p.steps_per_launch, static_cast<const double *>(d_in),
-                                                   static_cast<double *>(d_out), begin, end, static_cast<hipStream_t>(stream));
+        const hipError_t e = p.dtype == LORA_BF16
+                                 ? lora::launch_3d_bf16_lanes(p, p.steps_per_launch, d_in, d_out, begin, end, static_cast<hipStream_t>(stream))
+                                 : lora::launch_3d_lanes(p, p.steps_per_launch, static_cast<const double *>(d_in),
+                                                         static_cast<double *>(d_out), begin, end, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) {
             lora::set_last_error("fused register-resident 3D kernel launch", e);
             return LORA_EHIP;

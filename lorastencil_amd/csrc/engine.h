@@ -89,7 +89,7 @@ struct Plan {
     int stream3_pipe = 0;     // 3D plane-streaming kernel: 1 = every level consumes what was published one step earlier (one barrier per step, two buffers per level)
     int stream3_async = 0;    // 3D plane-streaming kernel: 1 = no workgroup barriers (neighbour-wave counters in LDS, private input rings)
     int stream3_slots = 0;    // 3D plane-streaming kernel: input plane slots of the LDS ring (0 = as many as fit)
-    int lanes3 = -1;          // 3D fp64 fused launches through the register-resident kernel (kernels_3d_lanes.hip: four applications per launch): -1 by grid size, 0 never, 1 always (star / separable box taps, reference boundary)
+    int lanes3 = -1;          // 3D fused launches through the register-resident kernels (kernels_3d_lanes.hip, fp64; kernels_3d_bf16_lanes.hip, bf16: four applications per launch): -1 by grid size, 0 never, 1 always (star / separable box taps, reference boundary)
     int lanes3_active = 0;    // resolved
     int fused_z_chunk = 0;    // 3D fused: output planes per workgroup (0 = auto: 32, shorter on small grids)
     int steps_per_launch_req = 0;  // 0 = auto, 1, 2 (2D / 3D), 4 (2D row-streaming kernel), 2 / 4 / 8 (1D)
@@ -158,6 +158,10 @@ hipError_t launch_3d_bf16(const Plan &p, const void *in, void *out, int begin, i
 const char *kernel_name_3d_bf16(const Plan &p);
 hipError_t launch_3d_bf16_fused2(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s);
 const char *kernel_name_3d_bf16_fused2(const Plan &p);
+// bf16, exactly separable box taps: K = 4 (or 2) applications per launch with the levels in registers (kernels_3d_bf16_lanes.hip)
+hipError_t launch_3d_bf16_lanes(const Plan &p, int K, const void *in, void *out, int begin, int end, hipStream_t s);
+const char *kernel_name_3d_bf16_lanes(const Plan &p);
+bool prepare_3d_bf16_lanes(const Plan &p);  // false: no workgroup of it fits a CU of the current device
 // bf16 box, two applications per launch, in-plane passes on v_mfma_f32_16x16x32_bf16 (LORA_VARIANT_MFMA)
 hipError_t launch_3d_bf16_mfma2(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s);
 const char *kernel_name_3d_bf16_mfma2(const Plan &p);

@@ -1,0 +1,588 @@
+// kernels_3d_bf16_lanes.hip -- FOUR applications of an exactly separable 3D radius-1 box per launch on bf16 grids, the
+// time levels held in registers (BASELINE config 5: box3d1r 768^3 bf16; no reference counterpart -- the reference is
+// fp64-only; the loop it replaces is 3d/gpu_box.cu:105-140 inside the time-step loop :208-212).
+//
+// Where round 3 left bf16 (profiles/r02_box3d1r_bf16_pmc.json): stencil3d_bf16_fused2_kernel applies two
+// sweeps per launch with level 1 as a bf16 LDS tile.  It is bound by the fp32 vector pipe -- 15.3 lane-instructions per
+// point and level where the arithmetic of the separable form is 9 multiply-adds and 1.5 conversions -- because every level
+// re-reads 12-element LDS windows, converts each element for up to three column pairs and rebuilds odd-aligned pairs.
+//
+// What the vector pipe charges (tools/probes/fp32_rate_probe.hip, profiles/r04_fp32_rate_probe.txt; SIMD time per wave
+// instruction at 1 / 2 / 4 waves per SIMD): v_fma_f32 / v_fmac_f32 5.0 / 2.5 / 1.3, v_pk_fma_f32 5.8 / 4.8 / 3.4 (two points:
+// no cheaper per point than the plain form, and only when four waves share the SIMD does the plain form reach its rate --
+// ONE wave issues an instruction every ~5 cycles whatever it is), DPP forms, shifts, v_cvt_pk_bf16_f32 and v_fma_f64 3.3.
+// So the kernel wants FOUR waves per SIMD (<= 128 VGPRs), plain fp32 multiply-adds, and few of the slow forms.
+//
+// As in kernels_3d_lanes.hip (fp64), a level never goes to LDS as a tile:
+//   * A lane owns the same R = 4 rows x 2 columns of a 64 x 128 tile at EVERY level: one packed bf16 pair (a dword) per
+//     row; 16 waves (1024 threads) share the tile, one workgroup per CU.  x-neighbours are the neighbouring lanes'
+//     registers (DPP wave_shr:1 / wave_shl:1 folded into the multiply-add that consumes them), y-neighbours the lane's own
+//     rows and, across waves, the x-PASSED form of each wave's first / last row (8 bytes per lane and level through LDS);
+//     z is streamed: per level and point TWO fp32 partial sums live between steps -- in a step the older one takes its
+//     dz = 2 tap, is rounded to bf16 (the level's completed plane) and is re-opened in place with the dz = 0 tap of the
+//     same U; the other takes its dz = 1 tap.  The two slots swap roles every step (the loop is unrolled by two).
+//   * The levels are SKEWED by one step: level l + 1 consumes in step p the plane level l completed in step p - 1 (a
+//     packed bf16 plane: R registers per level).  All K levels of a step are then independent of each other: every level
+//     publishes its edge rows before ONE barrier per step, and the scheduler has K independent chains to interleave.
+//     Price: K - 1 more steps per z-chunk (zc + 3 K - 1 instead of zc + 2 K).
+//   * Numerics are the contract of kernels_3d_bf16.hip / oracle_step_3d_bf16_sep: T = fma(c2, x+, fma(c1, x0, c0 x-))
+//     along x, U likewise along y over T, out along z over U, all fp32, ONE round-to-nearest-even to bf16 per level
+//     (v_cvt_pk_bf16_f32) -- so a launch is bit-identical to K single sweeps.  Unpacking a level's plane for the next level
+//     is a shift and a mask per pair.
+//   * Input planes: every wave fetches its own four rows of the next plane with ONE 1 KiB LDS-DMA (16 bytes per lane,
+//     whole 256-byte row pieces) into a private two-slot ring and picks its dwords up from there -- no staging registers.
+//     Output planes leave as dword stores through a range-checked buffer descriptor per row, issued at the START of the
+//     next step right behind the step's one s_waitcnt vmcnt(0): everything that wait covers (the DMA of this step's plane,
+//     the stores of the plane before) was issued a whole step earlier, and no count relies on the order in which loads
+//     and stores complete.
+//   * Halo semantics: cells of an intermediate level outside the interior are 0 at odd levels and the source
+//     buffer's own halo value at even ones (level 2 of four).  Rim tiles, and every tile in the steps whose planes lie
+//     outside the z range, run an EDGE copy of the step that forces them with a bit-field insert per pair; the level-2
+//     values come from the input array (while fused launches run every buffer carries buffer 0's halo) by a buffer load
+//     in which only the lanes holding such a cell make a memory request, issued at the start of the step.
+//
+// Taps: exactly separable 27-point boxes (TAPS3D_SEP: every box3d1r the reference's API can express, 3d/gpu_box.cu:158-164).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+
+#include "device_common.h"
+
+// Timing experiments for tools/probes/bf16_lanes_ablate.hip (results are WRONG with bits 1 .. 16 set): 1 no barriers, 2 no
+// stores, 4 no plane loads after the first, 8 no EDGE steps, 16 only EDGE steps; 32 = the taps as scalar operands (right
+// results, the form the first version of this kernel had: an fp32 instruction with a scalar operand issues at half rate)
+#ifndef LORA_BL_ABLATE
+#define LORA_BL_ABLATE 0
+#endif
+// -DLORA_BL_STAMP=n (tools/probes/bf16_lanes_ablate.hip): every wave adds up the s_memtime cycles phase n of its steps takes
+// (1 upper levels ahead of the barrier, 2 barrier, 3 behind it, 4 wait + stores + DMA, 5 lower levels ahead, 6 barrier,
+// 7 behind) and leaves the sum and its step count in a debug buffer; the shipped library has none of it
+#ifndef LORA_BL_STAMP
+#define LORA_BL_STAMP 0
+#endif
+#if LORA_BL_ABLATE & 32
+#define LORA_BL_TAP "s"
+#else
+#define LORA_BL_TAP "v"
+#endif
+
+namespace lora {
+
+namespace {
+
+constexpr int kTileW = 128;  // columns of a tile: 64 lanes x 2
+constexpr int kOutW = 120;   // output columns of a tile: lanes 2 .. 61
+
+typedef unsigned short u16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+struct ArgsBL {
+    const u16 *in;
+    u16 *out;
+    int h, m, n;
+    int ld;
+    long plane;
+    int z_begin, z_end;
+    int zc;
+    int tiles_x, tiles_y;
+#if LORA_BL_STAMP
+    long long *stamps;  // [workgroup][wave][2]: cycles of the stamped phase, steps
+#endif
+};
+struct TapsSep {
+    float c[3], b[3], a[3];
+};
+
+// The x-pass of a lane's four rows (four packed bf16 pairs -> eight fp32 sums), written out as the instructions it is.
+// Per row:  x0, x1 = the pair's halves as fp32 (a shift, a mask)
+//   t0 = fma(c2, x1, fma(c1, x0, c0 * x1[lane - 1]))        t1 = fma(c2, x0[lane + 1], fma(c1, x1, c0 * x0))
+// with the neighbour lanes' values taken as DPP operands of the multiply / multiply-add that consumes them (wave_shr:1 /
+// wave_shl:1, 0 beyond the wave's ends: lanes 0 and 63 hold cells that are never valid beyond level 0).  Why by hand:
+// hipcc folds a DPP move into v_mul_f32 but not into v_fmac_f32, its SLP pass packs the pair's multiply-adds into
+// v_pk_fma_f32 behind register moves -- both cost more than they save here (tools/probes/fp32_rate_probe.hip) -- and it
+// pads every asm statement with an s_nop, so the four rows are ONE statement.  A DPP operand must not be read within two
+// instructions of the VALU instruction that wrote it (the hardware does not interlock that, and the compiler cannot see into
+// an asm statement): the order below keeps two or more between them.  c0 / c2 are passed in VECTOR registers (a DPP
+// instruction takes no scalar operand), c1 in a scalar one.
+#define LORA_X1(N) "v_lshlrev_b32_e32 %[x0" #N "], 16, %[in" #N "]\n\t"
+#define LORA_X2(N) "v_and_b32_e32 %[x1" #N "], 0xffff0000, %[in" #N "]\n\t"
+#define LORA_X3(N) "v_mul_f32_e32 %[t1" #N "], %[c0], %[x0" #N "]\n\t"
+#define LORA_X4(N) "v_fmac_f32_e32 %[t1" #N "], %[c1], %[x1" #N "]\n\t"
+#define LORA_X5(N) "v_mul_f32_dpp %[t0" #N "], %[x1" #N "], %[c0] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define LORA_X6(N) "v_fmac_f32_e32 %[t0" #N "], %[c1], %[x0" #N "]\n\t"
+#define LORA_X7(N) "v_fmac_f32_e32 %[t0" #N "], %[c2], %[x1" #N "]\n\t"
+#define LORA_X8(N) "v_fmac_f32_dpp %[t1" #N "], %[x0" #N "], %[c2] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#if LORA_BL_ABLATE & 64  // (A/B: row after row -- every multiply-add right behind the instruction it depends on)
+#define LORA_XROW(N) LORA_X1(N) LORA_X2(N) LORA_X3(N) LORA_X4(N) LORA_X5(N) LORA_X6(N) LORA_X7(N) LORA_X8(N)
+#define LORA_XROWS LORA_XROW(a) LORA_XROW(b) LORA_XROW(c) LORA_XROW(d)
+#else  // the four rows interleaved: four independent chains, a dependent instruction four slots behind its producer
+#define LORA_XALL(X) X(a) X(b) X(c) X(d)
+#define LORA_XROWS LORA_XALL(LORA_X1) LORA_XALL(LORA_X2) LORA_XALL(LORA_X3) LORA_XALL(LORA_X4) LORA_XALL(LORA_X5) LORA_XALL(LORA_X6) LORA_XALL(LORA_X7) LORA_XALL(LORA_X8)
+#endif
+__device__ __forceinline__ void xpass_rows(const unsigned (&in)[4], float c0v, float c1, float c2v, float (&t)[4][2]) {
+    float x0a, x1a, x0b, x1b, x0c, x1c, x0d, x1d;
+    asm(LORA_XROWS
+        : [x0a] "=&v"(x0a), [x1a] "=&v"(x1a), [t0a] "=&v"(t[0][0]), [t1a] "=&v"(t[0][1]),
+          [x0b] "=&v"(x0b), [x1b] "=&v"(x1b), [t0b] "=&v"(t[1][0]), [t1b] "=&v"(t[1][1]),
+          [x0c] "=&v"(x0c), [x1c] "=&v"(x1c), [t0c] "=&v"(t[2][0]), [t1c] "=&v"(t[2][1]),
+          [x0d] "=&v"(x0d), [x1d] "=&v"(x1d), [t0d] "=&v"(t[3][0]), [t1d] "=&v"(t[3][1])
+        : [ina] "v"(in[0]), [inb] "v"(in[1]), [inc] "v"(in[2]), [ind] "v"(in[3]), [c0] "v"(c0v), [c1] LORA_BL_TAP(c1), [c2] "v"(c2v));
+}
+// The z-pass of one row of a lane (two points) and its rounding: per point `cur` (dz = 0, 1 taps in) takes its last tap and
+// is the level's completed value, `nxt` takes its dz = 1 tap, `cur` is opened again with the dz = 0 tap of the same u; the
+// two completed values leave as one packed bf16 pair (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN).  The
+// completed value as a three-address v_fma_f32: with the two-address v_fmac_f32 the compiler ties it to cur's register and
+// then needs a copy per point and step to bring the re-opened sum back to it around the loop.
+__device__ __forceinline__ unsigned zpass_row(float u0, float u1, float a0, float a1, float a2, float &cur0, float &nxt0, float &cur1,
+                                              float &nxt1) {
+    float o0, o1;
+    unsigned v;
+    asm("v_fma_f32 %[o0], %[a2], %[u0], %[cur0]\n\t"
+        "v_fma_f32 %[o1], %[a2], %[u1], %[cur1]\n\t"
+        "v_fmac_f32_e32 %[nxt0], %[a1], %[u0]\n\t"
+        "v_fmac_f32_e32 %[nxt1], %[a1], %[u1]\n\t"
+        "v_mul_f32_e32 %[cur0], %[a0], %[u0]\n\t"
+        "v_mul_f32_e32 %[cur1], %[a0], %[u1]\n\t"
+        "v_cvt_pk_bf16_f32 %[v], %[o0], %[o1]"
+        : [o0] "=&v"(o0), [o1] "=&v"(o1), [v] "=v"(v), [cur0] "+v"(cur0), [nxt0] "+v"(nxt0), [cur1] "+v"(cur1), [nxt1] "+v"(nxt1)
+        : [u0] "v"(u0), [u1] "v"(u1), [a0] LORA_BL_TAP(a0), [a1] LORA_BL_TAP(a1), [a2] LORA_BL_TAP(a2));
+    return v;
+}
+
+// Step p of a chunk whose first output plane is k0 takes input plane zin = k0 - K + p.  Level L (1 .. K) consumes the
+// plane level L - 1 completed in the step before and completes its own plane zin - 2 L + 1; level K is the output: plane
+// k0 + p - 3 K + 1, stored at the start of step p + 1.
+template <int K, int NW>
+__global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const ArgsBL a, const TapsSep W) {
+    constexpr int R = 4;            // rows of a lane = rows of one LDS-DMA piece (4 x 256 bytes)
+    constexpr int TH = R * NW;      // rows of a tile
+    constexpr int OH = TH - 2 * K;  // output rows of a tile
+    static_assert(K == 2 || K == 4, "an even number of applications (fused launches start at even steps)");
+    // x-passed first / last row of every wave and level (written ahead of a half-step's barrier, read behind it)
+    __shared__ __attribute__((aligned(16))) float edge_rows[K][NW][2][kTileW];
+    // input planes: per wave a private ring of two 1 KiB pieces (its four rows x 256 bytes of a plane)
+    __shared__ __attribute__((aligned(16))) unsigned ring[2][NW][R][kTileW / 2];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
+    // workgroup -> (chunk, tile): the tiles on the rim of the grid first (they run the slower EDGE steps throughout)
+    const int TX = a.tiles_x, TY = a.tiles_y, chunks = (a.z_end - a.z_begin + a.zc - 1) / a.zc;
+    int chunk, tx, ty;
+    if (TX < 3 || TY < 3) {
+        const int per_chunk = TX * TY;
+        chunk = lin / per_chunk;
+        const int rem = lin - chunk * per_chunk;
+        ty = rem / TX;
+        tx = rem - ty * TX;
+    } else {
+        const int rim = 2 * TX + 2 * (TY - 2), inner = (TX - 2) * (TY - 2);
+        if (lin < rim * chunks) {
+            chunk = lin / rim;
+            const int idx = lin - chunk * rim;
+            if (idx < 2 * TX) {
+                ty = idx < TX ? 0 : TY - 1;
+                tx = idx < TX ? idx : idx - TX;
+            } else {
+                const int k = idx - 2 * TX;
+                ty = 1 + (k >> 1);
+                tx = (k & 1) ? TX - 1 : 0;
+            }
+        } else {
+            const int l2 = lin - rim * chunks;
+            chunk = l2 / inner;
+            const int idx = l2 - chunk * inner;
+            ty = 1 + idx / (TX - 2);
+            tx = 1 + idx - (ty - 1) * (TX - 2);
+        }
+    }
+    const int k0 = a.z_begin + chunk * a.zc;
+    const int zc = min(a.zc, a.z_end - k0);
+    const int X0 = tx * kOutW - 4, Y0 = ty * OH - K;  // interior coordinates of the tile's first column / row
+    // this lane's cells: rows Y0 + R wv + r (r = 0 .. R - 1), columns X0 + 2 lane, + 1; padded: + 2 rows, + 4 columns,
+    // clamped into the padded array (clamped cells only feed cells outside the interior, which EDGE forces, or nothing)
+    const int col = X0 + 2 * lane;
+    unsigned rowoff[R];  // uniform: padded row x ld, in bytes
+#pragma unroll
+    for (int r = 0; r < R; ++r) rowoff[r] = 2u * (unsigned) (min(max(Y0 + R * wv + r + 2, 0), a.m + 3) * a.ld);
+    const int up = max(wv - 1, 0), dn = min(wv + 1, NW - 1);  // (the tile's outermost rows are never valid beyond level 0)
+    const unsigned plane_bytes = 2u * (unsigned) a.plane;
+    // the DMA piece of this lane: row lane / 16 of the wave's four, 16-byte chunk lane % 16 of the tile's 256-byte row
+    // (padded column X0 + 4 + 8 (lane % 16): a multiple of 8 elements; chunks beyond the padded row re-read its last one)
+    const unsigned dma_off = 2u * (unsigned) (min(max(Y0 + R * wv + (lane >> 4) + 2, 0), a.m + 3) * a.ld +
+                                              min(X0 + 4 + 8 * (lane & 15), a.n));
+
+    // stores: lanes 2 .. 61 write interior columns col, col + 1 of rows K .. TH - K - 1 of the tile (n is a multiple of 8:
+    // a pair never straddles the end of a row)
+    const unsigned st_off = (lane >= 2 && lane < 62 && col >= 0 && col < a.n) ? 2u * (unsigned) (col + 4) : 0x80000000u;
+    bool st_row[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int trow = R * wv + r;
+        st_row[r] = trow >= K && trow < TH - K && Y0 + trow < a.m;
+    }
+
+    // EDGE: which of this lane's cells are interior cells -- in x as a mask over the pair's two halves, in y per row
+    const bool xy_rim = X0 < 0 || X0 + kTileW > a.n || Y0 < 0 || Y0 + TH > a.m;  // (uniform over the workgroup)
+    const unsigned colmask = ((unsigned) col < (unsigned) a.n ? 0x0000ffffu : 0u) | ((unsigned) (col + 1) < (unsigned) a.n ? 0xffff0000u : 0u);
+    // byte offset of the lane's pair inside a padded row -- for the halo loads of the EDGE steps: lanes whose pair lies
+    // inside the interior in x ask for nothing unless the whole row or plane is outside
+    const unsigned ld_off = 2u * (unsigned) min(max(col + 4, 0), a.n + 6);
+    const unsigned ld_off_rim = colmask != 0xffffffffu ? ld_off : 0x80000000u;
+    bool row_in[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) row_in[r] = (unsigned) (Y0 + R * wv + r) < (unsigned) a.m;
+
+    // Per level and point two fp32 sums, slots 0 / 1; in a step of phase P (= p mod 2, a compile-time constant of the
+    // step's copy) acc[l][P] holds the plane that completes (dz = 0, 1 taps in) and acc[l][1 - P] the one above it (dz = 0).
+    float acc[K][2][R][2];
+#pragma unroll
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[l][q][r][0] = acc[l][q][r][1] = 0.0f;
+    unsigned done[K][R];  // done[l], l >= 1: the plane level l completed in the step before (packed bf16 pairs)
+#pragma unroll
+    for (int l = 0; l < K; ++l)
+#pragma unroll
+        for (int r = 0; r < R; ++r) done[l][r] = 0u;
+    unsigned outp[R];  // the output plane (level K) a step completes: stored in the middle of the step
+
+    auto issue_plane = [&](int p, int slot) {  // this wave's four rows of input plane p of the chunk -> ring[slot][wv]
+        const u16 *src = a.in + (long) min(max(k0 - K + p + 1, 0), a.h + 1) * a.plane;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(src), 0, plane_bytes, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *) &ring[slot][wv][0][0], 16, dma_off, 0, 0, 0);
+    };
+    auto store_plane = [&](int p_done) {  // the output plane completed in step p_done
+        const int o = p_done - 3 * K + 1;
+        const bool live = o >= 0 && o < zc;
+        u16 *const dst = a.out + (long) (k0 + max(o, 0) + 1) * a.plane;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                reinterpret_cast<char *>(dst) + rowoff[r], 0, (live && st_row[r]) ? 2u * (unsigned) (a.n + 8) : 0u, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(outp[r], rs, st_off, 0, 0);
+        }
+    };
+    issue_plane(0, 0);
+    // LDS byte address of this lane's dword of its wave's piece in slot 0 (slot 1: + 16 KB, row r: + 256 bytes)
+    static_assert(sizeof(ring[0]) == 64 * 256, "the slot stride is 64 x 256 bytes: ds_read2st64_b32 offsets");
+    const unsigned ring_addr = (unsigned) (size_t) (__attribute__((address_space(3))) void *) &ring[0][wv][0][lane];
+    // The nine taps live in VECTOR registers: on gfx950 an fp32 multiply-add with a scalar (constant-bus) operand issues at
+    // HALF the rate of the all-VGPR form -- v_fmac_f32 acc += s * v: 2.9 cycles of SIMD time per wave instruction at four
+    // waves per SIMD, acc += v * v: 1.3 - 1.9; v_mul_f32 3.3 against 1.35 (profiles/r04_fp32_rate_probe.txt)
+#if LORA_BL_ABLATE & 32
+    const float c1t = W.c[1], b0t = W.b[0], b1t = W.b[1], b2t = W.b[2], a0t = W.a[0], a1t = W.a[1], a2t = W.a[2];
+    float c0t = W.c[0], c2t = W.c[2];
+    asm volatile("" : "+v"(c0t), "+v"(c2t));
+#else
+    float c0t = W.c[0], c1t = W.c[1], c2t = W.c[2], b0t = W.b[0], b1t = W.b[1], b2t = W.b[2], a0t = W.a[0], a1t = W.a[1], a2t = W.a[2];
+    asm volatile("" : "+v"(c0t), "+v"(c1t), "+v"(c2t), "+v"(b0t), "+v"(b1t), "+v"(b2t), "+v"(a0t), "+v"(a1t), "+v"(a2t));
+#endif
+
+#if LORA_BL_STAMP
+    long long stamp_sum = 0, stamp_t0 = 0;
+    int stamp_n = 0;
+#define LORA_BL_T0(n)                                                   \
+    if constexpr (LORA_BL_STAMP == (n)) {                               \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        stamp_t0 = __builtin_amdgcn_s_memtime();                        \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    }
+#define LORA_BL_T1(n)                                                   \
+    if constexpr (LORA_BL_STAMP == (n)) {                               \
+        __builtin_amdgcn_sched_barrier(0);                              \
+        stamp_sum += __builtin_amdgcn_s_memtime() - stamp_t0;           \
+        stamp_n += 1;                                                   \
+        __builtin_amdgcn_sched_barrier(0);                              \
+    }
+#else
+#define LORA_BL_T0(n)
+#define LORA_BL_T1(n)
+#endif
+    auto step = [&](const int p, auto phase_tag, auto edge_tag) {
+        constexpr int P = decltype(phase_tag)::value, Q = 1 - P;
+        constexpr bool EDGE = decltype(edge_tag)::value;
+        const int zin = k0 - K + p;
+        unsigned hv[R];     // EDGE: what level-2 cells outside the interior are forced to
+        float tk[K][2][2];  // per level: x-passed row 1, and row R - 1's y-pass short of the lower neighbour's row
+        // level l + 1 from the plane of level l (l = 0: the input plane): everything that needs no other wave's row
+        auto ahead = [&](auto level_tag) {
+            constexpr int l = decltype(level_tag)::value;
+            unsigned raw[R];
+            if constexpr (l == 0) {
+                // Picked up here, not at the top of the step: four registers less while the upper levels run.  And by hand:
+                // the compiler knows that the DMA writes `ring` but not WHICH slot, so a plain read of slot P waits
+                // (s_waitcnt vmcnt) for the DMA of slot Q issued a moment ago -- the whole latency of the prefetch, every
+                // step.  Plane p landed before the step's own vmcnt(0) above.
+                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                u32x2 lo, hi;
+                asm volatile("ds_read2st64_b32 %0, %2 offset0:%3 offset1:%4\n\t"
+                             "ds_read2st64_b32 %1, %2 offset0:%5 offset1:%6\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(lo), "=&v"(hi)
+                             : "v"(ring_addr), "n"(P * 64), "n"(P * 64 + 1), "n"(P * 64 + 2), "n"(P * 64 + 3)
+                             : "memory");
+                raw[0] = lo.x;
+                raw[1] = lo.y;
+                raw[2] = hi.x;
+                raw[3] = hi.y;
+            }
+            const unsigned(&in)[R] = l == 0 ? raw : done[l];
+            float t[R][2];
+            xpass_rows(in, c0t, c1t, c2t, t);
+            *reinterpret_cast<f2 *>(&edge_rows[l][wv][0][2 * lane]) = (f2){t[0][0], t[0][1]};
+            *reinterpret_cast<f2 *>(&edge_rows[l][wv][1][2 * lane]) = (f2){t[R - 1][0], t[R - 1][1]};
+#pragma unroll
+            for (int r = 1; r < R - 1; ++r) {
+                float u[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) u[c] = fmaf(b2t, t[r + 1][c], fmaf(b1t, t[r][c], b0t * t[r - 1][c]));
+                const unsigned v = zpass_row(u[0], u[1], a0t, a1t, a2t, acc[l][P][r][0], acc[l][Q][r][0], acc[l][P][r][1], acc[l][Q][r][1]);
+                if (l == K - 1)
+                    outp[r] = v;
+                else
+                    done[l + 1][r] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                tk[l][0][c] = t[1][c];
+                tk[l][1][c] = fmaf(b1t, t[R - 1][c], b0t * t[R - 2][c]);
+            }
+            // one level at a time: eight points are parallelism enough, and a scheduler that interleaves levels keeps
+            // several sets of x-passed rows alive (the kernel then spills at its 128 registers)
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // ... and behind the barrier rows 0 and R - 1, with the neighbours' rows (and the wave's own first row again: cheaper
+        // than two more registers per level held across the barrier)
+        auto behind = [&](auto level_tag) {
+            constexpr int l = decltype(level_tag)::value;
+            const f2 vu = *reinterpret_cast<const f2 *>(&edge_rows[l][up][1][2 * lane]);
+            const f2 t0 = *reinterpret_cast<const f2 *>(&edge_rows[l][wv][0][2 * lane]);
+            const f2 vd = *reinterpret_cast<const f2 *>(&edge_rows[l][dn][0][2 * lane]);
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {  // e = 0: row 0 (above it the upper neighbour's last row), e = 1: row R - 1
+                const int r = e == 0 ? 0 : R - 1;
+                float u[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    u[c] = e == 0 ? fmaf(b2t, tk[l][0][c], fmaf(b1t, c == 0 ? t0.x : t0.y, b0t * (c == 0 ? vu.x : vu.y)))
+                                  : fmaf(b2t, c == 0 ? vd.x : vd.y, tk[l][1][c]);
+                const unsigned v = zpass_row(u[0], u[1], a0t, a1t, a2t, acc[l][P][r][0], acc[l][Q][r][0], acc[l][P][r][1], acc[l][Q][r][1]);
+                if (l == K - 1)
+                    outp[r] = v;
+                else
+                    done[l + 1][r] = v;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // The step runs the levels top down (level l + 1 has consumed done[l + 1] when level l overwrites it) in two halves
+        // with a barrier each: the x-passed rows a wave keeps for behind the barrier are then two levels' worth, not four, and
+        // one copy of edge_rows serves (a half's rows are rewritten a whole step later, two barriers on).
+        LORA_BL_T0(1);
+        if constexpr (K == 4) {
+            ahead(std::integral_constant<int, 3>{});
+            ahead(std::integral_constant<int, 2>{});
+        } else {
+            ahead(std::integral_constant<int, 1>{});
+        }
+        LORA_BL_T1(1);
+        LORA_BL_T0(2);
+        if constexpr (LORA_BL_ABLATE & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        LORA_BL_T1(2);
+        LORA_BL_T0(3);
+        if constexpr (K == 4) {
+            behind(std::integral_constant<int, 3>{});
+            behind(std::integral_constant<int, 2>{});
+        } else {
+            behind(std::integral_constant<int, 1>{});
+        }
+        LORA_BL_T1(3);
+        LORA_BL_T0(4);
+        // The output plane of this step is complete.  Everything issued at this point of the step before has had a whole
+        // step to complete -- the DMA of plane p, which the lower half is about to read, and the stores of the plane before
+        // (and an EDGE step's halo loads, which it waited for itself) -- so the one wait of the step costs nothing, and no
+        // count relies on the order in which loads and stores complete.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (!(LORA_BL_ABLATE & 2)) store_plane(p);
+        if constexpr (!(LORA_BL_ABLATE & 4)) issue_plane(p + 1, Q);
+        if constexpr (EDGE && K > 2) {
+            // level 2 completes plane zin - 3 in this step; its cells outside the interior take the input's values there
+            const int z = zin - 3;
+            const bool z_in = (unsigned) z < (unsigned) a.h;
+            const u16 *src = a.in + (long) min(max(z + 1, 0), a.h + 1) * a.plane;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(src), 0, plane_bytes, 0x00020000);
+#pragma unroll
+            for (int r = 0; r < R; ++r)
+                hv[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (z_in && row_in[r]) ? ld_off_rim : ld_off, rowoff[r], 0);
+        }
+        LORA_BL_T1(4);
+        LORA_BL_T0(5);
+        if constexpr (K == 4) {
+            ahead(std::integral_constant<int, 1>{});
+            ahead(std::integral_constant<int, 0>{});
+        } else {
+            ahead(std::integral_constant<int, 0>{});
+        }
+        LORA_BL_T1(5);
+        LORA_BL_T0(6);
+        if constexpr (LORA_BL_ABLATE & 1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); else
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        LORA_BL_T1(6);
+        LORA_BL_T0(7);
+        if constexpr (K == 4) {
+            behind(std::integral_constant<int, 1>{});
+            behind(std::integral_constant<int, 0>{});
+        } else {
+            behind(std::integral_constant<int, 0>{});
+        }
+        LORA_BL_T1(7);
+        if constexpr (EDGE) {
+            // the plane level L just completed, zin - 2 L + 1: its cells outside the interior are forced -- to 0 at odd
+            // levels, at level 2 to the source buffer's own value there
+#pragma unroll
+            for (int L = 1; L < K; ++L) {
+                const int z = zin - 2 * L + 1;
+                const bool z_in = (unsigned) z < (unsigned) a.h;
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const unsigned keep = (z_in && row_in[r]) ? colmask : 0u;
+                    done[L][r] = L % 2 == 0 ? ((done[L][r] & keep) | (hv[r] & ~keep)) : (done[L][r] & keep);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // Steps whose intermediate planes can lie outside the z range: level L's plane zin - 2 L + 1 is below plane 0 while
+    // p < 3 K - 3 - k0 (L = K - 1) and beyond plane h - 1 from p = h - k0 + K + 1 on (L = 1).  Tiles on the rim in x / y run
+    // the EDGE copy throughout.  Steps come in turns of two (one per phase); the EDGE ranges are widened to whole turns, and
+    // a chunk may run one step past its last plane (loads clamped, stores switched off).
+    const int steps = zc + 3 * K - 1, turns = (steps + 1) / 2;
+    int p1 = min(max(3 * K - 3 - k0, 0), steps), p2 = min(max(a.h - k0 + K + 1, p1), steps);
+    if (xy_rim) p1 = steps;
+    if (LORA_BL_ABLATE & 8) p1 = 0, p2 = steps;
+    if (LORA_BL_ABLATE & 16) p1 = steps;
+    const int t1 = min((p1 + 1) / 2, turns), t2 = min(max(p2 / 2, t1), turns);
+    auto turn = [&](const int p, auto edge_tag) {
+        step(p, std::integral_constant<int, 0>{}, edge_tag);
+        step(p + 1, std::integral_constant<int, 1>{}, edge_tag);
+    };
+    int t = 0;
+    for (; t < t1; ++t) turn(2 * t, std::true_type{});
+    for (; t < t2; ++t) turn(2 * t, std::false_type{});
+    for (; t < turns; ++t) turn(2 * t, std::true_type{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the DMA of a plane nobody reads: it must not land in a dead workgroup's LDS)
+#if LORA_BL_STAMP
+    if (lane == 0) {
+        a.stamps[((long) blockIdx.x * NW + wv) * 2] = stamp_sum;
+        a.stamps[((long) blockIdx.x * NW + wv) * 2 + 1] = ((long long) xy_rim << 32) | stamp_n;
+    }
+#endif
+}
+#undef LORA_BL_T0
+#undef LORA_BL_T1
+
+template <int K, int NW>
+hipError_t launch_t(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s) {
+    constexpr int OH = 4 * NW - 2 * K;
+    auto kernel = stencil3d_bf16_lanes_kernel<K, NW>;
+    static int per_cu[64] = {0};  // resolved once per device (and with it the kernel itself: lora_plan_create's share)
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    if (per_cu[dev] == 0) {
+        int nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NW * 64, 0) != hipSuccess || nb < 1) {
+            (void) hipGetLastError();
+            nb = -1;  // no workgroup of this kernel fits a CU of this device (it wants the whole 160 KB of LDS)
+        }
+        per_cu[dev] = nb;
+    }
+    if (per_cu[dev] < 0) return hipErrorLaunchOutOfResources;
+    if (end <= begin) return hipSuccess;  // prepare_3d_bf16_lanes()
+    ArgsBL a;
+    a.in = static_cast<const u16 *>(in);
+    a.out = static_cast<u16 *>(out);
+    a.h = p.dims[0];
+    a.m = p.dims[1];
+    a.n = p.dims[2];
+    a.ld = a.n + 8;
+    a.plane = (long) (a.m + 4) * (a.n + 8);
+    if (a.plane * 2 >= (1L << 31)) return hipErrorInvalidValue;  // 32-bit byte offsets inside a plane
+    a.z_begin = begin;
+    a.z_end = end;
+    a.tiles_x = (a.n + kOutW - 1) / kOutW;
+    a.tiles_y = (a.m + OH - 1) / OH;
+    const long tiles = (long) a.tiles_x * a.tiles_y;
+    // z-chunks: a chunk runs 3 K - 1 steps beyond its own planes, so chunks should be long; but the launch should fill the
+    // CUs (one workgroup each) in whole rounds.  Same cost model as kernels_3d_lanes.hip (rounds_eff x steps per chunk).
+    if (p.fused_z_chunk > 0) {
+        a.zc = std::min(p.fused_z_chunk, end - begin);
+    } else {
+        const long slots = (long) std::max(per_cu[dev], 1) * cus, depth = end - begin;
+        double best = 0.0;
+        long best_c = 1;
+        for (long c = 1; c <= std::max(1L, depth / (4 * K)); ++c) {
+            const long zc = (depth + c - 1) / c, wgs = tiles * ((depth + zc - 1) / zc);
+            const double x = (double) wgs / (double) slots;
+            const double whole = std::floor(x), part = x - whole;
+            const double rounds = 1.03 * whole + (part > 1e-9 ? 0.65 + 0.4 * part : 0.0);
+            const double cost = rounds * (double) (zc + 3 * K - 1);
+            if (best == 0.0 || cost < best) {
+                best = cost;
+                best_c = c;
+            }
+        }
+        a.zc = (int) ((depth + best_c - 1) / best_c);
+    }
+    const long nblocks = tiles * ((end - begin + a.zc - 1) / a.zc);
+    if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
+    TapsSep w;
+    for (int k = 0; k < 3; ++k) {
+        w.c[k] = p.sep[k];
+        w.b[k] = p.sep[3 + k];
+        w.a[k] = p.sep[6 + k];
+    }
+#if LORA_BL_STAMP
+    extern long long *g_bl_stamps;
+    extern long g_bl_stamp_blocks;
+    a.stamps = g_bl_stamps;
+    g_bl_stamp_blocks = nblocks;
+#endif
+    hipLaunchKernelGGL(kernel, dim3((unsigned) nblocks), dim3(NW * 64), 0, s, a, w);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// K = 4 (or 2) applications in one launch over interior planes [begin, end); exactly separable box taps, reference boundary
+hipError_t launch_3d_bf16_lanes(const Plan &p, int K, const void *in, void *out, int begin, int end, hipStream_t s) {
+    if (p.boundary != LORA_BC_REFERENCE || p.dtype != LORA_BF16 || p.tapset != TAPS3D_SEP) return hipErrorNotSupported;
+    if (K == 4) return launch_t<4, 16>(p, in, out, begin, end, s);
+    if (K == 2) return launch_t<2, 16>(p, in, out, begin, end, s);
+    return hipErrorInvalidValue;
+}
+
+// one-time host work (kernel resolution, residency query) of the plan's instantiations; no launch.  False when no
+// workgroup of the kernel fits a CU of the current device (the plan then keeps the tile kernels).
+bool prepare_3d_bf16_lanes(const Plan &p) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void) hipGetLastError();
+        return true;  // no device: nothing to ask (plans made on a host without one only answer host-side queries)
+    }
+    return launch_3d_bf16_lanes(p, 4, nullptr, nullptr, 0, 0, nullptr) == hipSuccess &&
+           launch_3d_bf16_lanes(p, 2, nullptr, nullptr, 0, 0, nullptr) == hipSuccess;
+}
+
+const char *kernel_name_3d_bf16_lanes(const Plan &) { return "stencil3d_bf16_lanes_kernel"; }
+
+}  // namespace lora

@@ -83,6 +83,26 @@ def main():
                     e["fp64_issue_frac"] = e["SQ_INSTS_VALU_FMA_F64"]["mean"] * 4.0 / (cyc * 1024.0)
                 if "SQ_VALU_MFMA_BUSY_CYCLES" in cs:
                     e["mfma_busy"] = e["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"] / (cyc * 1024.0)
+                if "SQ_LDS_IDX_ACTIVE" in cs:
+                    # LDS-array cycles summed over the CUs, of the cycles 256 CUs had
+                    e["lds_active"] = e["SQ_LDS_IDX_ACTIVE"]["mean"] / (cyc * 256.0)
+                if "SQ_WAIT_INST_ANY" in cs:
+                    e["wait_inst_frac"] = e["SQ_WAIT_INST_ANY"]["mean"] / e["SQ_WAVE_CYCLES"]["mean"]
+                if "SQ_WAIT_ANY" in cs:
+                    e["wait_any_frac"] = e["SQ_WAIT_ANY"]["mean"] / e["SQ_WAVE_CYCLES"]["mean"]
+            # EXECUTED arithmetic, wave-instructions per launch by kind (SQ_INSTS_VALU_FMA_F64 counts v_fma_f64 only: the
+            # nested-profile 2D kernel reads 11.2 per point = its 10 FMAs x the halo lanes; adds and multiplies are their own
+            # counters).  Flops = 64 lanes x (2 per FMA, 1 per add / multiply).
+            kinds = {}
+            for prec in ("F64", "F32"):
+                for op in ("FMA", "ADD", "MUL"):
+                    c = f"SQ_INSTS_VALU_{op}_{prec}"
+                    if c in cs:
+                        kinds[f"{op.lower()}_{prec.lower()}"] = e[c]["mean"]
+            if kinds:
+                e["valu_insts_by_kind"] = kinds
+            if "SQ_INSTS_VALU" in cs:
+                e["valu_insts"] = e["SQ_INSTS_VALU"]["mean"]
             summary[k] = e
         out = os.path.join(prof, f"{args.tag}_pmc.json")
         json.dump(summary, open(out, "w"), indent=1, sort_keys=True)
@@ -98,6 +118,11 @@ def main():
                                        "waves_per_simd": round(best["waves_per_simd"], 2) if "waves_per_simd" in best else None,
                                        "fp64_issue_frac": round(best["fp64_issue_frac"], 3) if "fp64_issue_frac" in best else None,
                                        "clock_ghz": round(best["clock_ghz"], 3) if "clock_ghz" in best else None,
+                                       "lds_active": round(best["lds_active"], 3) if "lds_active" in best else None,
+                                       "wait_inst_frac": round(best["wait_inst_frac"], 3) if "wait_inst_frac" in best else None,
+                                       "valu_insts": round(best["valu_insts"]) if "valu_insts" in best else None,
+                                       "valu_insts_by_kind": ({k: round(v) for k, v in best["valu_insts_by_kind"].items()}
+                                                              if "valu_insts_by_kind" in best else None),
                                        "source": f"profiles/{args.tag}_pmc.json"}
                 json.dump(t, open(tpath, "w"), indent=1, sort_keys=True)
                 print("traffic", args.traffic_key, t[args.traffic_key])
