@@ -61,6 +61,11 @@
 #ifndef LORA_BL_STAMP
 #define LORA_BL_STAMP 0
 #endif
+// bit 128 of LORA_BL_ABLATE: the y- and z-passes of a lane's column pair as packed instructions (v_pk_mul_f32 /
+// v_pk_fma_f32: two points each, 29 % fewer vector instructions per step; same results).  Measured SLOWER in this kernel:
+// 1034 - 1039 us per launch at 768^3 against 865 - 887 for the plain form (profiles/r04_bf16_lanes_packed_ab.txt), although
+// the bare instruction sequence is 13 % faster packed (profiles/r04_bf16_level_probe.txt) -- kept for the record only.
+#define LORA_BL_PACKED ((LORA_BL_ABLATE & 128) != 0)
 #if LORA_BL_ABLATE & 32
 #define LORA_BL_TAP "s"
 #else
@@ -121,35 +126,141 @@ struct TapsSep {
 #define LORA_XALL(X) X(a) X(b) X(c) X(d)
 #define LORA_XROWS LORA_XALL(LORA_X1) LORA_XALL(LORA_X2) LORA_XALL(LORA_X3) LORA_XALL(LORA_X4) LORA_XALL(LORA_X5) LORA_XALL(LORA_X6) LORA_XALL(LORA_X7) LORA_XALL(LORA_X8)
 #endif
-__device__ __forceinline__ void xpass_rows(const unsigned (&in)[4], float c0v, float c1, float c2v, float (&t)[4][2]) {
+__device__ __forceinline__ void xpass_rows(const unsigned (&in)[4], float c0v, float c1, float c2v, f2 (&t)[4]) {
     float x0a, x1a, x0b, x1b, x0c, x1c, x0d, x1d;
     asm(LORA_XROWS
-        : [x0a] "=&v"(x0a), [x1a] "=&v"(x1a), [t0a] "=&v"(t[0][0]), [t1a] "=&v"(t[0][1]),
-          [x0b] "=&v"(x0b), [x1b] "=&v"(x1b), [t0b] "=&v"(t[1][0]), [t1b] "=&v"(t[1][1]),
-          [x0c] "=&v"(x0c), [x1c] "=&v"(x1c), [t0c] "=&v"(t[2][0]), [t1c] "=&v"(t[2][1]),
-          [x0d] "=&v"(x0d), [x1d] "=&v"(x1d), [t0d] "=&v"(t[3][0]), [t1d] "=&v"(t[3][1])
+        : [x0a] "=&v"(x0a), [x1a] "=&v"(x1a), [t0a] "=&v"(t[0].x), [t1a] "=&v"(t[0].y),
+          [x0b] "=&v"(x0b), [x1b] "=&v"(x1b), [t0b] "=&v"(t[1].x), [t1b] "=&v"(t[1].y),
+          [x0c] "=&v"(x0c), [x1c] "=&v"(x1c), [t0c] "=&v"(t[2].x), [t1c] "=&v"(t[2].y),
+          [x0d] "=&v"(x0d), [x1d] "=&v"(x1d), [t0d] "=&v"(t[3].x), [t1d] "=&v"(t[3].y)
         : [ina] "v"(in[0]), [inb] "v"(in[1]), [inc] "v"(in[2]), [ind] "v"(in[3]), [c0] "v"(c0v), [c1] LORA_BL_TAP(c1), [c2] "v"(c2v));
 }
-// The z-pass of one row of a lane (two points) and its rounding: per point `cur` (dz = 0, 1 taps in) takes its last tap and
-// is the level's completed value, `nxt` takes its dz = 1 tap, `cur` is opened again with the dz = 0 tap of the same u; the
-// two completed values leave as one packed bf16 pair (v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN).  The
-// completed value as a three-address v_fma_f32: with the two-address v_fmac_f32 the compiler ties it to cur's register and
-// then needs a copy per point and step to bring the re-opened sum back to it around the loop.
-__device__ __forceinline__ unsigned zpass_row(float u0, float u1, float a0, float a1, float a2, float &cur0, float &nxt0, float &cur1,
-                                              float &nxt1) {
-    float o0, o1;
-    unsigned v;
-    asm("v_fma_f32 %[o0], %[a2], %[u0], %[cur0]\n\t"
-        "v_fma_f32 %[o1], %[a2], %[u1], %[cur1]\n\t"
-        "v_fmac_f32_e32 %[nxt0], %[a1], %[u0]\n\t"
-        "v_fmac_f32_e32 %[nxt1], %[a1], %[u1]\n\t"
-        "v_mul_f32_e32 %[cur0], %[a0], %[u0]\n\t"
-        "v_mul_f32_e32 %[cur1], %[a0], %[u1]\n\t"
-        "v_cvt_pk_bf16_f32 %[v], %[o0], %[o1]"
-        : [o0] "=&v"(o0), [o1] "=&v"(o1), [v] "=v"(v), [cur0] "+v"(cur0), [nxt0] "+v"(nxt0), [cur1] "+v"(cur1), [nxt1] "+v"(nxt1)
-        : [u0] "v"(u0), [u1] "v"(u1), [a0] LORA_BL_TAP(a0), [a1] LORA_BL_TAP(a1), [a2] LORA_BL_TAP(a2));
-    return v;
+// The taps in vector registers.  Plain form: nine.  Packed form: the x-pass's three and the y / z taps as three register
+// PAIRS (b0, b1), (b2, a0), (a1, a2) -- a packed instruction takes its tap from either half of a pair (op_sel), so six taps
+// cost six registers, not the twelve of six splat pairs.
+struct TapsV {
+    float c0, c1, c2, b0, b1, b2, a0, a1, a2;
+    f2 b01, b2a0, a12;
+};
+typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned round_pair(const f2 o) {  // one v_cvt_pk_bf16_f32 (round-to-nearest-even, NaN stays NaN)
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf2));
 }
+// y-pass and z-pass of TWO rows of a lane (two points each), per point in the contract's order:
+//   u = fma(b2, t[r + 1], fma(b1, t[r], b0 * t[r - 1]))
+//   o = fma(a2, u, cur)   the level's completed value (cur had its dz = 0, 1 taps);   nxt = fma(a1, u, nxt);   cur = a0 * u
+// and the completed values leave as packed bf16 pairs.
+// Packed form: a lane's two columns sit in an aligned register pair, every line above is ONE v_pk instruction on the pair
+// (two points), the tap is the low or high half of a tap pair (op_sel / op_sel_hi on the first operand).  By hand because
+// hipcc materialises every splat tap as a register pair of its own (twelve registers more: the kernel spills at its 128).
+// The two rows are interleaved: a packed instruction is never read by the very next one (the pipe forwards a packed result
+// to a dependent packed instruction only with an instruction between them -- hipcc itself puts an s_nop there).
+// Plain form: the same arithmetic as v_mul / v_fmac / v_fma_f32 per point; the completed value as a THREE-address v_fma_f32
+// (with the two-address v_fmac_f32 the compiler ties it to cur's register and then needs a copy per point and step to
+// bring the re-opened sum back around the loop).
+#define LORA_LO "op_sel_hi:[0,1,1]"                  /* first operand: its low half for both points */
+#define LORA_HI "op_sel:[1,0,0] op_sel_hi:[1,1,1]"   /* first operand: its high half for both points */
+__device__ __forceinline__ void yz_rows2(const f2 tA_m, const f2 tA_0, const f2 tA_p, const f2 tB_m, const f2 tB_0, const f2 tB_p, const TapsV &T,
+                                         f2 &curA, f2 &nxtA, f2 &curB, f2 &nxtB, unsigned &vA, unsigned &vB) {
+#if LORA_BL_PACKED
+    f2 uA, uB, oA, oB;
+    asm("v_pk_mul_f32 %[uA], %[b01], %[tAm] op_sel_hi:[0,1]\n\t"
+        "v_pk_mul_f32 %[uB], %[b01], %[tBm] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %[uA], %[b01], %[tA0], %[uA] " LORA_HI "\n\t"
+        "v_pk_fma_f32 %[uB], %[b01], %[tB0], %[uB] " LORA_HI "\n\t"
+        "v_pk_fma_f32 %[uA], %[b2a0], %[tAp], %[uA] " LORA_LO "\n\t"
+        "v_pk_fma_f32 %[uB], %[b2a0], %[tBp], %[uB] " LORA_LO "\n\t"
+        "v_pk_fma_f32 %[oA], %[a12], %[uA], %[curA] " LORA_HI "\n\t"
+        "v_pk_fma_f32 %[oB], %[a12], %[uB], %[curB] " LORA_HI "\n\t"
+        "v_pk_fma_f32 %[nxtA], %[a12], %[uA], %[nxtA] " LORA_LO "\n\t"
+        "v_pk_fma_f32 %[nxtB], %[a12], %[uB], %[nxtB] " LORA_LO "\n\t"
+        "v_pk_mul_f32 %[curA], %[b2a0], %[uA] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_mul_f32 %[curB], %[b2a0], %[uB] op_sel:[1,0] op_sel_hi:[1,1]"
+        : [uA] "=&v"(uA), [uB] "=&v"(uB), [oA] "=&v"(oA), [oB] "=&v"(oB), [curA] "+v"(curA), [nxtA] "+v"(nxtA), [curB] "+v"(curB), [nxtB] "+v"(nxtB)
+        : [tAm] "v"(tA_m), [tA0] "v"(tA_0), [tAp] "v"(tA_p), [tBm] "v"(tB_m), [tB0] "v"(tB_0), [tBp] "v"(tB_p), [b01] "v"(T.b01), [b2a0] "v"(T.b2a0),
+          [a12] "v"(T.a12));
+    vA = round_pair(oA);
+    vB = round_pair(oB);
+#else
+    const f2 t3[2][3] = {{tA_m, tA_0, tA_p}, {tB_m, tB_0, tB_p}};
+    f2 *const cur[2] = {&curA, &curB}, *const nxt[2] = {&nxtA, &nxtB};
+    unsigned *const v[2] = {&vA, &vB};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float u0 = fmaf(T.b2, t3[q][2].x, fmaf(T.b1, t3[q][1].x, T.b0 * t3[q][0].x));
+        const float u1 = fmaf(T.b2, t3[q][2].y, fmaf(T.b1, t3[q][1].y, T.b0 * t3[q][0].y));
+        float o0, o1;
+        asm("v_fma_f32 %[o0], %[a2], %[u0], %[cur0]\n\t"
+            "v_fma_f32 %[o1], %[a2], %[u1], %[cur1]\n\t"
+            "v_fmac_f32_e32 %[nxt0], %[a1], %[u0]\n\t"
+            "v_fmac_f32_e32 %[nxt1], %[a1], %[u1]\n\t"
+            "v_mul_f32_e32 %[cur0], %[a0], %[u0]\n\t"
+            "v_mul_f32_e32 %[cur1], %[a0], %[u1]\n\t"
+            "v_cvt_pk_bf16_f32 %[v], %[o0], %[o1]"
+            : [o0] "=&v"(o0), [o1] "=&v"(o1), [v] "=v"(*v[q]), [cur0] "+v"(cur[q]->x), [nxt0] "+v"(nxt[q]->x), [cur1] "+v"(cur[q]->y),
+              [nxt1] "+v"(nxt[q]->y)
+            : [u0] "v"(u0), [u1] "v"(u1), [a0] LORA_BL_TAP(T.a0), [a1] LORA_BL_TAP(T.a1), [a2] LORA_BL_TAP(T.a2));
+    }
+#endif
+}
+// The same for a lane's first and last row behind the barrier: row 0 with the upper neighbour's last row above it (vu) and
+// the wave's own rows 0 (t0, re-read from LDS) and 1 (t1, kept); row R - 1 as u = fma(b2, vd, part) with the lower
+// neighbour's first row vd and part = fma(b1, t[R - 1], b0 * t[R - 2]) computed ahead of the barrier.
+__device__ __forceinline__ void yz_edges(const f2 vu, const f2 t0, const f2 t1, const f2 vd, const f2 part, const TapsV &T, f2 &curA, f2 &nxtA,
+                                         f2 &curB, f2 &nxtB, unsigned &vA, unsigned &vB) {
+#if LORA_BL_PACKED
+    f2 uA, uB, oA, oB;
+    asm("v_pk_mul_f32 %[uA], %[b01], %[vu] op_sel_hi:[0,1]\n\t"
+        "v_pk_fma_f32 %[uB], %[b2a0], %[vd], %[part] " LORA_LO "\n\t"
+        "v_pk_fma_f32 %[uA], %[b01], %[t0], %[uA] " LORA_HI "\n\t"
+        "v_pk_fma_f32 %[oB], %[a12], %[uB], %[curB] " LORA_HI "\n\t"
+        "v_pk_fma_f32 %[uA], %[b2a0], %[t1], %[uA] " LORA_LO "\n\t"
+        "v_pk_fma_f32 %[nxtB], %[a12], %[uB], %[nxtB] " LORA_LO "\n\t"
+        "v_pk_fma_f32 %[oA], %[a12], %[uA], %[curA] " LORA_HI "\n\t"
+        "v_pk_mul_f32 %[curB], %[b2a0], %[uB] op_sel:[1,0] op_sel_hi:[1,1]\n\t"
+        "v_pk_fma_f32 %[nxtA], %[a12], %[uA], %[nxtA] " LORA_LO "\n\t"
+        "v_pk_mul_f32 %[curA], %[b2a0], %[uA] op_sel:[1,0] op_sel_hi:[1,1]"
+        : [uA] "=&v"(uA), [uB] "=&v"(uB), [oA] "=&v"(oA), [oB] "=&v"(oB), [curA] "+v"(curA), [nxtA] "+v"(nxtA), [curB] "+v"(curB), [nxtB] "+v"(nxtB)
+        : [vu] "v"(vu), [t0] "v"(t0), [t1] "v"(t1), [vd] "v"(vd), [part] "v"(part), [b01] "v"(T.b01), [b2a0] "v"(T.b2a0), [a12] "v"(T.a12));
+    vA = round_pair(oA);
+    vB = round_pair(oB);
+#else
+    f2 *const cur[2] = {&curA, &curB}, *const nxt[2] = {&nxtA, &nxtB};
+    unsigned *const v[2] = {&vA, &vB};
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const float u0 = q == 0 ? fmaf(T.b2, t1.x, fmaf(T.b1, t0.x, T.b0 * vu.x)) : fmaf(T.b2, vd.x, part.x);
+        const float u1 = q == 0 ? fmaf(T.b2, t1.y, fmaf(T.b1, t0.y, T.b0 * vu.y)) : fmaf(T.b2, vd.y, part.y);
+        float o0, o1;
+        asm("v_fma_f32 %[o0], %[a2], %[u0], %[cur0]\n\t"
+            "v_fma_f32 %[o1], %[a2], %[u1], %[cur1]\n\t"
+            "v_fmac_f32_e32 %[nxt0], %[a1], %[u0]\n\t"
+            "v_fmac_f32_e32 %[nxt1], %[a1], %[u1]\n\t"
+            "v_mul_f32_e32 %[cur0], %[a0], %[u0]\n\t"
+            "v_mul_f32_e32 %[cur1], %[a0], %[u1]\n\t"
+            "v_cvt_pk_bf16_f32 %[v], %[o0], %[o1]"
+            : [o0] "=&v"(o0), [o1] "=&v"(o1), [v] "=v"(*v[q]), [cur0] "+v"(cur[q]->x), [nxt0] "+v"(nxt[q]->x), [cur1] "+v"(cur[q]->y),
+              [nxt1] "+v"(nxt[q]->y)
+            : [u0] "v"(u0), [u1] "v"(u1), [a0] LORA_BL_TAP(T.a0), [a1] LORA_BL_TAP(T.a1), [a2] LORA_BL_TAP(T.a2));
+    }
+#endif
+}
+// part = fma(b1, t[R - 1], b0 * t[R - 2]): what row R - 1's y-pass can do ahead of the barrier
+__device__ __forceinline__ f2 ypart(const f2 tm, const f2 t0, const TapsV &T) {
+#if LORA_BL_PACKED
+    f2 u;
+    asm("v_pk_mul_f32 %[u], %[b01], %[tm] op_sel_hi:[0,1]\n\t"
+        "s_nop 0\n\t"
+        "v_pk_fma_f32 %[u], %[b01], %[t0], %[u] " LORA_HI
+        : [u] "=&v"(u)
+        : [tm] "v"(tm), [t0] "v"(t0), [b01] "v"(T.b01));
+    return u;
+#else
+    return (f2){fmaf(T.b1, t0.x, T.b0 * tm.x), fmaf(T.b1, t0.y, T.b0 * tm.y)};
+#endif
+}
+#undef LORA_LO
+#undef LORA_HI
 
 // Step p of a chunk whose first output plane is k0 takes input plane zin = k0 - K + p.  Level L (1 .. K) consumes the
 // plane level L - 1 completed in the step before and completes its own plane zin - 2 L + 1; level K is the output: plane
@@ -161,7 +272,11 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
     constexpr int OH = TH - 2 * K;  // output rows of a tile
     static_assert(K == 2 || K == 4, "an even number of applications (fused launches start at even steps)");
     // x-passed first / last row of every wave and level (written ahead of a half-step's barrier, read behind it)
-    __shared__ __attribute__((aligned(16))) float edge_rows[K][NW][2][kTileW];
+    // Wave w keeps its rows in slot w + 1 of NW + 2, so that the upper neighbour's last row, the wave's own two rows and the
+    // lower neighbour's first row are at fixed offsets 0 / 128 / 256 / 384 floats from ONE per-lane address (slots 0 and
+    // NW + 1 are never written: what the top and the bottom wave read there feeds rows that are never valid).
+    __shared__ __attribute__((aligned(16))) float edge_rows[K][NW + 2][2][kTileW];
+    constexpr int kLevelStride = (NW + 2) * 2 * kTileW;  // floats
     // input planes: per wave a private ring of two 1 KiB pieces (its four rows x 256 bytes of a plane)
     __shared__ __attribute__((aligned(16))) unsigned ring[2][NW][R][kTileW / 2];
 
@@ -207,7 +322,7 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
     unsigned rowoff[R];  // uniform: padded row x ld, in bytes
 #pragma unroll
     for (int r = 0; r < R; ++r) rowoff[r] = 2u * (unsigned) (min(max(Y0 + R * wv + r + 2, 0), a.m + 3) * a.ld);
-    const int up = max(wv - 1, 0), dn = min(wv + 1, NW - 1);  // (the tile's outermost rows are never valid beyond level 0)
+    float *const edge_base = &edge_rows[0][wv][1][2 * lane];  // the upper neighbour's last row (slot wv), level 0
     const unsigned plane_bytes = 2u * (unsigned) a.plane;
     // the DMA piece of this lane: row lane / 16 of the wave's four, 16-byte chunk lane % 16 of the tile's 256-byte row
     // (padded column X0 + 4 + 8 (lane % 16): a multiple of 8 elements; chunks beyond the padded row re-read its last one)
@@ -216,6 +331,7 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
 
     // stores: lanes 2 .. 61 write interior columns col, col + 1 of rows K .. TH - K - 1 of the tile (n is a multiple of 8:
     // a pair never straddles the end of a row)
+    // (byte offset inside a padded row; the row itself is the scalar offset of the store; out of range = no store)
     const unsigned st_off = (lane >= 2 && lane < 62 && col >= 0 && col < a.n) ? 2u * (unsigned) (col + 4) : 0x80000000u;
     bool st_row[R];
 #pragma unroll
@@ -237,13 +353,13 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
 
     // Per level and point two fp32 sums, slots 0 / 1; in a step of phase P (= p mod 2, a compile-time constant of the
     // step's copy) acc[l][P] holds the plane that completes (dz = 0, 1 taps in) and acc[l][1 - P] the one above it (dz = 0).
-    float acc[K][2][R][2];
+    f2 acc[K][2][R];  // (a lane's two columns side by side: an aligned register pair, what the packed instructions take)
 #pragma unroll
     for (int l = 0; l < K; ++l)
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int r = 0; r < R; ++r) acc[l][q][r][0] = acc[l][q][r][1] = 0.0f;
+            for (int r = 0; r < R; ++r) acc[l][q][r] = (f2){0.0f, 0.0f};
     unsigned done[K][R];  // done[l], l >= 1: the plane level l completed in the step before (packed bf16 pairs)
 #pragma unroll
     for (int l = 0; l < K; ++l)
@@ -251,20 +367,26 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
         for (int r = 0; r < R; ++r) done[l][r] = 0u;
     unsigned outp[R];  // the output plane (level K) a step completes: stored in the middle of the step
 
+    // (Plane addresses as 32 x 32 -> 64-bit products of a plane index and plane_bytes: two scalar instructions; a plane's
+    // descriptor covers the whole plane and a row is picked by the scalar offset of the access -- per-row descriptors and
+    // 64 x 64-bit address arithmetic were 65 scalar instructions per step, a third of them for the four stores.)
     auto issue_plane = [&](int p, int slot) {  // this wave's four rows of input plane p of the chunk -> ring[slot][wv]
-        const u16 *src = a.in + (long) min(max(k0 - K + p + 1, 0), a.h + 1) * a.plane;
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(src), 0, plane_bytes, 0x00020000);
+        const unsigned z = (unsigned) min(max(k0 - K + p + 1, 0), a.h + 1);
+        const char *src = reinterpret_cast<const char *>(a.in) + (unsigned long long) z * plane_bytes;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(src), 0, plane_bytes, 0x00020000);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void *) &ring[slot][wv][0][0], 16, dma_off, 0, 0, 0);
     };
+    unsigned st_bytes[R];  // what a row's descriptor lets through: the plane, or nothing for rows this wave does not store
+#pragma unroll
+    for (int r = 0; r < R; ++r) st_bytes[r] = st_row[r] ? plane_bytes : 0u;
     auto store_plane = [&](int p_done) {  // the output plane completed in step p_done
         const int o = p_done - 3 * K + 1;
-        const bool live = o >= 0 && o < zc;
-        u16 *const dst = a.out + (long) (k0 + max(o, 0) + 1) * a.plane;
+        const bool live = (unsigned) o < (unsigned) zc;
+        char *const dst = reinterpret_cast<char *>(a.out) + (unsigned long long) (unsigned) (k0 + max(o, 0) + 1) * plane_bytes;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                reinterpret_cast<char *>(dst) + rowoff[r], 0, (live && st_row[r]) ? 2u * (unsigned) (a.n + 8) : 0u, 0x00020000);
-            __builtin_amdgcn_raw_buffer_store_b32(outp[r], rs, st_off, 0, 0);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(dst, 0, live ? st_bytes[r] : 0u, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b32(outp[r], rs, st_off, rowoff[r], 0);
         }
     };
     issue_plane(0, 0);
@@ -274,13 +396,13 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
     // The nine taps live in VECTOR registers: on gfx950 an fp32 multiply-add with a scalar (constant-bus) operand issues at
     // HALF the rate of the all-VGPR form -- v_fmac_f32 acc += s * v: 2.9 cycles of SIMD time per wave instruction at four
     // waves per SIMD, acc += v * v: 1.3 - 1.9; v_mul_f32 3.3 against 1.35 (profiles/r04_fp32_rate_probe.txt)
+    TapsV T = {W.c[0], W.c[1], W.c[2], W.b[0], W.b[1], W.b[2], W.a[0], W.a[1], W.a[2], {W.b[0], W.b[1]}, {W.b[2], W.a[0]}, {W.a[1], W.a[2]}};
 #if LORA_BL_ABLATE & 32
-    const float c1t = W.c[1], b0t = W.b[0], b1t = W.b[1], b2t = W.b[2], a0t = W.a[0], a1t = W.a[1], a2t = W.a[2];
-    float c0t = W.c[0], c2t = W.c[2];
-    asm volatile("" : "+v"(c0t), "+v"(c2t));
+    asm volatile("" : "+v"(T.c0), "+v"(T.c2));  // (DPP operands are vector registers whatever the rest is)
+#elif LORA_BL_PACKED
+    asm volatile("" : "+v"(T.c0), "+v"(T.c1), "+v"(T.c2), "+v"(T.b01), "+v"(T.b2a0), "+v"(T.a12));
 #else
-    float c0t = W.c[0], c1t = W.c[1], c2t = W.c[2], b0t = W.b[0], b1t = W.b[1], b2t = W.b[2], a0t = W.a[0], a1t = W.a[1], a2t = W.a[2];
-    asm volatile("" : "+v"(c0t), "+v"(c1t), "+v"(c2t), "+v"(b0t), "+v"(b1t), "+v"(b2t), "+v"(a0t), "+v"(a1t), "+v"(a2t));
+    asm volatile("" : "+v"(T.c0), "+v"(T.c1), "+v"(T.c2), "+v"(T.b0), "+v"(T.b1), "+v"(T.b2), "+v"(T.a0), "+v"(T.a1), "+v"(T.a2));
 #endif
 
 #if LORA_BL_STAMP
@@ -308,13 +430,15 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
         constexpr bool EDGE = decltype(edge_tag)::value;
         const int zin = k0 - K + p;
         unsigned hv[R];     // EDGE: what level-2 cells outside the interior are forced to
-        float tk[K][2][2];  // per level: x-passed row 1, and row R - 1's y-pass short of the lower neighbour's row
+        f2 tk[K][2];  // per level: x-passed row 1, and row R - 1's y-pass short of the lower neighbour's row
+        unsigned raw[R];  // the input plane's dwords of this lane
         // level l + 1 from the plane of level l (l = 0: the input plane): everything that needs no other wave's row
         auto ahead = [&](auto level_tag) {
             constexpr int l = decltype(level_tag)::value;
-            unsigned raw[R];
             if constexpr (l == 0) {
-                // Picked up here, not at the top of the step: four registers less while the upper levels run.  And by hand:
+                // Picked up here, not at the top of the step: four registers less while the upper levels run.  Issue and wait
+                // in ONE statement: split in two (the read a level earlier, to hide its round trip) the compiler is free to
+                // copy the destination registers before the data has arrived -- wrong planes, seen.  And by hand at all:
                 // the compiler knows that the DMA writes `ring` but not WHICH slot, so a plain read of slot P waits
                 // (s_waitcnt vmcnt) for the DMA of slot Q issued a moment ago -- the whole latency of the prefetch, every
                 // step.  Plane p landed before the step's own vmcnt(0) above.
@@ -332,50 +456,55 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
                 raw[3] = hi.y;
             }
             const unsigned(&in)[R] = l == 0 ? raw : done[l];
-            float t[R][2];
-            xpass_rows(in, c0t, c1t, c2t, t);
-            *reinterpret_cast<f2 *>(&edge_rows[l][wv][0][2 * lane]) = (f2){t[0][0], t[0][1]};
-            *reinterpret_cast<f2 *>(&edge_rows[l][wv][1][2 * lane]) = (f2){t[R - 1][0], t[R - 1][1]};
-#pragma unroll
-            for (int r = 1; r < R - 1; ++r) {
-                float u[2];
-#pragma unroll
-                for (int c = 0; c < 2; ++c) u[c] = fmaf(b2t, t[r + 1][c], fmaf(b1t, t[r][c], b0t * t[r - 1][c]));
-                const unsigned v = zpass_row(u[0], u[1], a0t, a1t, a2t, acc[l][P][r][0], acc[l][Q][r][0], acc[l][P][r][1], acc[l][Q][r][1]);
-                if (l == K - 1)
-                    outp[r] = v;
-                else
-                    done[l + 1][r] = v;
+            f2 t[R];
+            xpass_rows(in, T.c0, T.c1, T.c2, t);
+            *reinterpret_cast<f2 *>(edge_base + l * kLevelStride + 128) = t[0];
+            *reinterpret_cast<f2 *>(edge_base + l * kLevelStride + 256) = t[R - 1];
+            {
+                static_assert(R == 4, "rows 1 and 2 are the two inner rows");
+                unsigned v1, v2;
+                yz_rows2(t[0], t[1], t[2], t[1], t[2], t[3], T, acc[l][P][1], acc[l][Q][1], acc[l][P][2], acc[l][Q][2], v1, v2);
+                if (l == K - 1) {
+                    outp[1] = v1;
+                    outp[2] = v2;
+                } else {
+                    done[l + 1][1] = v1;
+                    done[l + 1][2] = v2;
+                }
             }
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                tk[l][0][c] = t[1][c];
-                tk[l][1][c] = fmaf(b1t, t[R - 1][c], b0t * t[R - 2][c]);
-            }
+            tk[l][0] = t[1];
+            tk[l][1] = ypart(t[R - 2], t[R - 1], T);
             // one level at a time: eight points are parallelism enough, and a scheduler that interleaves levels keeps
             // several sets of x-passed rows alive (the kernel then spills at its 128 registers)
             __builtin_amdgcn_sched_barrier(0);
         };
         // ... and behind the barrier rows 0 and R - 1, with the neighbours' rows (and the wave's own first row again: cheaper
         // than two more registers per level held across the barrier)
-        auto behind = [&](auto level_tag) {
+        // The three rows a level needs from LDS behind the barrier: the upper neighbour's last row, the wave's own first
+        // row, the lower neighbour's first row.  A half-step's reads are all issued before the first is used: the second
+        // level's rows travel while the first level computes (one LDS round trip per half-step on a wave's critical path,
+        // not one per level).
+        struct Rows3 {
+            f2 vu, t0, vd;
+        };
+        auto fetch = [&](auto level_tag) {
             constexpr int l = decltype(level_tag)::value;
-            const f2 vu = *reinterpret_cast<const f2 *>(&edge_rows[l][up][1][2 * lane]);
-            const f2 t0 = *reinterpret_cast<const f2 *>(&edge_rows[l][wv][0][2 * lane]);
-            const f2 vd = *reinterpret_cast<const f2 *>(&edge_rows[l][dn][0][2 * lane]);
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {  // e = 0: row 0 (above it the upper neighbour's last row), e = 1: row R - 1
-                const int r = e == 0 ? 0 : R - 1;
-                float u[2];
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    u[c] = e == 0 ? fmaf(b2t, tk[l][0][c], fmaf(b1t, c == 0 ? t0.x : t0.y, b0t * (c == 0 ? vu.x : vu.y)))
-                                  : fmaf(b2t, c == 0 ? vd.x : vd.y, tk[l][1][c]);
-                const unsigned v = zpass_row(u[0], u[1], a0t, a1t, a2t, acc[l][P][r][0], acc[l][Q][r][0], acc[l][P][r][1], acc[l][Q][r][1]);
-                if (l == K - 1)
-                    outp[r] = v;
-                else
-                    done[l + 1][r] = v;
+            Rows3 q;
+            q.vu = *reinterpret_cast<const f2 *>(edge_base + l * kLevelStride);
+            q.t0 = *reinterpret_cast<const f2 *>(edge_base + l * kLevelStride + 128);
+            q.vd = *reinterpret_cast<const f2 *>(edge_base + l * kLevelStride + 384);
+            return q;
+        };
+        auto behind = [&](auto level_tag, const Rows3 &q) {
+            constexpr int l = decltype(level_tag)::value;
+            unsigned v0, v3;
+            yz_edges(q.vu, q.t0, tk[l][0], q.vd, tk[l][1], T, acc[l][P][0], acc[l][Q][0], acc[l][P][R - 1], acc[l][Q][R - 1], v0, v3);
+            if (l == K - 1) {
+                outp[0] = v0;
+                outp[R - 1] = v3;
+            } else {
+                done[l + 1][0] = v0;
+                done[l + 1][R - 1] = v3;
             }
             __builtin_amdgcn_sched_barrier(0);
         };
@@ -396,10 +525,12 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
         LORA_BL_T1(2);
         LORA_BL_T0(3);
         if constexpr (K == 4) {
-            behind(std::integral_constant<int, 3>{});
-            behind(std::integral_constant<int, 2>{});
+            const Rows3 q3 = fetch(std::integral_constant<int, 3>{}), q2 = fetch(std::integral_constant<int, 2>{});
+            __builtin_amdgcn_sched_barrier(0);
+            behind(std::integral_constant<int, 3>{}, q3);
+            behind(std::integral_constant<int, 2>{}, q2);
         } else {
-            behind(std::integral_constant<int, 1>{});
+            behind(std::integral_constant<int, 1>{}, fetch(std::integral_constant<int, 1>{}));
         }
         LORA_BL_T1(3);
         LORA_BL_T0(4);
@@ -414,8 +545,8 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
             // level 2 completes plane zin - 3 in this step; its cells outside the interior take the input's values there
             const int z = zin - 3;
             const bool z_in = (unsigned) z < (unsigned) a.h;
-            const u16 *src = a.in + (long) min(max(z + 1, 0), a.h + 1) * a.plane;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<u16 *>(src), 0, plane_bytes, 0x00020000);
+            const char *src = reinterpret_cast<const char *>(a.in) + (unsigned long long) (unsigned) min(max(z + 1, 0), a.h + 1) * plane_bytes;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(src), 0, plane_bytes, 0x00020000);
 #pragma unroll
             for (int r = 0; r < R; ++r)
                 hv[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (z_in && row_in[r]) ? ld_off_rim : ld_off, rowoff[r], 0);
@@ -435,10 +566,12 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
         LORA_BL_T1(6);
         LORA_BL_T0(7);
         if constexpr (K == 4) {
-            behind(std::integral_constant<int, 1>{});
-            behind(std::integral_constant<int, 0>{});
+            const Rows3 q1 = fetch(std::integral_constant<int, 1>{}), q0 = fetch(std::integral_constant<int, 0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            behind(std::integral_constant<int, 1>{}, q1);
+            behind(std::integral_constant<int, 0>{}, q0);
         } else {
-            behind(std::integral_constant<int, 0>{});
+            behind(std::integral_constant<int, 0>{}, fetch(std::integral_constant<int, 0>{}));
         }
         LORA_BL_T1(7);
         if constexpr (EDGE) {

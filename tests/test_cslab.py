@@ -123,6 +123,21 @@ def test_loopback_slabs_dirichlet_and_bf16(L):
     slabs.run(6)
     out = slabs.store(np.zeros_like(bits))
     assert np.array_equal(out, O.run_bf16(shape, bits, 6))
+    # bf16 z-slabs through the register-resident kernel: four per launch (4 + 4 + 2 + 1), ghost zones of 4 x E planes
+    dims = (64, 30, 248)
+    rng = np.random.default_rng(3)
+    bits = O.to_bf16(rng.standard_normal(O.padded_shape(shape, dims)))
+    w = O.effective_weights(shape)
+    w = w / w.sum()
+    for nranks, every, flags in ((4, 2, 16), (3, 1, 0)):
+        slabs = cslab.SlabSet(shape, dims, nranks, comms=cslab.loopback_comms(nranks), dtype="bf16", weights=w, exchange_every=every,
+                              flags=flags, options={"steps_per_launch": 4})
+        assert slabs.info(0).apps_per_launch == 4 and slabs.info(0).ghost == 4 * every
+        slabs.load(bits)
+        slabs.run(5)
+        slabs.run(6)
+        out = slabs.store(np.zeros_like(bits))
+        assert np.array_equal(out, O.run_bf16(shape, bits, 11, weights=w)), (nranks, every, flags)
 
 
 @pytest.mark.gpu

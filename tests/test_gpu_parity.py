@@ -946,6 +946,38 @@ def test_bf16_fused_two_step_launches_equal_step_by_step(L, O, shape, dims):
     assert np.array_equal(dst.view(torch.int16).cpu().numpy().view(np.uint16), exp)
 
 
+@pytest.mark.parametrize("dims", [(3, 5, 8), (9, 31, 248), (40, 61, 128), (37, 64, 360), (12, 57, 968), (30, 113, 240), (64, 7, 16)])
+def test_bf16_register_resident_kernel_equals_step_by_step(L, O, dims):
+    """stencil3d_bf16_lanes_kernel (four applications per launch, the levels in registers, every level rounded to bf16 as a
+    single sweep stores it): runs of 4 .. 13 sweeps -- full launches, a two-application tail, single sweeps -- equal the
+    step-by-step bf16 oracle bit for bit on the whole padded buffer; tiny, ragged, rim-only and several-tile grids, every
+    z-chunk length; general separable taps; taps that are not separable keep the tile kernels."""
+    shape = "box3d1r"
+    rng = np.random.default_rng(41)
+    bits = O.to_bf16(rng.standard_normal(O.padded_shape(shape, dims)))
+    w = O.effective_weights(shape)
+    w = w / w.sum()
+    plan = L.Plan(shape, dims, dtype="bf16").set_weights(w).set_option("steps_per_launch", 4)
+    assert plan.kernel_name == "stencil3d_bf16_lanes_kernel" and plan.get_option("steps_per_launch") == 4
+    for t in (4, 5, 8, 9, 13):
+        exp = O.run_bf16(shape, bits, t, weights=w)
+        for opts in ({"steps_per_launch": 4}, {"steps_per_launch": 4, "fused_z_chunk": 3}, {"lanes3": 1, "fused_z_chunk": 16}):
+            assert np.array_equal(plan_run_bf16(L, shape, bits, t, weights=w, options=opts), exp), (dims, t, opts)
+    # any exactly separable taps: a (x) b (x) c of random factors
+    a, b, c = (rng.standard_normal(3).astype(np.float32) for _ in range(3))
+    ws = (a[:, None, None] * b[None, :, None]).astype(np.float32)[..., None] * c[None, None, None, :]
+    ws = np.asarray(ws, dtype=np.float32).reshape(27).astype(np.float64) / 8.0
+    sp = L.Plan(shape, dims, dtype="bf16").set_weights(ws).set_option("steps_per_launch", 4)
+    if sp.kernel_name == "stencil3d_bf16_lanes_kernel":  # (the exact rank-1 test may refuse products that rounded)
+        assert np.array_equal(plan_run_bf16(L, shape, bits, 9, weights=ws, options={"steps_per_launch": 4}),
+                              O.run_bf16(shape, bits, 9, weights=ws))
+    wr = rng.standard_normal(27)
+    wr /= np.abs(wr).sum()
+    general = L.Plan(shape, dims, dtype="bf16").set_weights(wr).set_option("steps_per_launch", 4)
+    assert general.kernel_name == "stencil3d_bf16_fused2_kernel" and general.get_option("steps_per_launch") == 2
+    assert L.Plan("star3d1r", dims, dtype="bf16").set_option("steps_per_launch", 4).kernel_name == "stencil3d_bf16_fused2_kernel"
+
+
 @pytest.mark.parametrize("dims", [(8, 28, 64), (9, 31, 248), (5, 3, 8), (37, 64, 360), (40, 61, 128)])
 def test_bf16_matrix_pipe_variant_matches_its_contract(L, O, dims):
     """LORA_VARIANT_MFMA of a bf16 box plan (kernels_3d_bf16_mfma.hip: v_mfma_f32_16x16x32_bf16, two applications per
@@ -1386,7 +1418,7 @@ def test_grids_beyond_32_bit_indexing(L, O, shape, dims, dtype):
             flat[lo:hi] = ((r * 31 + inner[None, :] * 7) % 97).to(tdt)
     dst = torch.zeros_like(src)
     w = O.effective_weights(shape)  # integer taps on integers 0..96: every partial sum is exact, whatever the order
-    win = {1: (5000,), 2: (70, 140), 3: (6, 20, 136)}[len(dims)]
+    win = {1: (5000,), 2: (70, 140), 3: (12, 24, 136)}[len(dims)]  # (3D: four sweeps per launch leave a 6 x 18 x 130 core)
     corners = [tuple(0 for _ in dims), tuple(d - wd for d, wd in zip(dims, win)),
                tuple((d - wd) // 2 for d, wd in zip(dims, win))]
 
@@ -1456,13 +1488,29 @@ def test_full_size_bf16_box3d1r_768(L, O):
     # the fused kernel (default for runs of >= 4 sweeps) == two single sweeps through a zero-halo buffer, everywhere;
     # normalised taps keep the random field finite in bf16
     plan.set_weights(w27 / 36.0)
-    assert plan.kernel_name == "stencil3d_bf16_fused2_kernel"
+    assert plan.kernel_name == "stencil3d_bf16_lanes_kernel" and plan.get_option("steps_per_launch") == 4
     dst.zero_()
     plan.step(src, dst)
     two = src.clone()
     plan.step(dst, two)
     fused = src.clone()
-    plan.step2(src, fused)
+    plan.step2(src, fused)           # the two-application launch of the same kernel (tails of a run)
+    torch.cuda.synchronize()
+    assert torch.equal(fused.view(torch.int16), two.view(torch.int16))
+    # four applications per launch (the register-resident kernel, BASELINE config 5's default) == four single sweeps
+    # through buffers whose halo alternates between 0 and the input's, everywhere
+    plan.step(two, dst)              # dst = level 3 with a zero halo
+    four = src.clone()
+    plan.step(dst, four)
+    fused4 = src.clone()
+    plan.stepk(src, fused4)
+    torch.cuda.synchronize()
+    assert torch.equal(fused4.view(torch.int16), four.view(torch.int16))
+    # ... and the round-3 tile kernel (two per launch: option lanes3 = 0) still agrees
+    old = L.Plan(shape, dims, dtype="bf16").set_weights(w27 / 36.0).set_option("lanes3", 0)
+    assert old.kernel_name == "stencil3d_bf16_fused2_kernel"
+    fused.copy_(src)
+    old.step2(src, fused)
     torch.cuda.synchronize()
     assert torch.equal(fused.view(torch.int16), two.view(torch.int16))
 

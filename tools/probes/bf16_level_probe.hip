@@ -34,7 +34,7 @@ __device__ __forceinline__ void xpass_rows(const unsigned (&in)[4], float c0v, f
 }
 
 // MODE 0: plain y / z;  1: packed y / z;  2: x-pass only;  3: plain y / z only;  4: packed y / z only
-template <int MODE, int THREADS>
+template <int MODE, int THREADS, int UNROLL = 1>
 __global__ __launch_bounds__(THREADS) void probe(long long *cycles, float *sink, float c0, float c1, float c2) {
     unsigned in[4];
     f2 cur[2], nxt[2];
@@ -47,7 +47,9 @@ __global__ __launch_bounds__(THREADS) void probe(long long *cycles, float *sink,
     for (int r = 0; r < 4; ++r) t[r] = (f2){0.1f * r, 0.2f};
     __syncthreads();
     const long long t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 0; it < ITER; ++it) {
+    for (int it = 0; it < ITER / UNROLL; ++it) {
+#pragma unroll
+      for (int un = 0; un < UNROLL; ++un) {
         if constexpr (MODE <= 2) xpass_rows(in, c0, c1, c2, t);
         if constexpr (MODE != 2) {
 #pragma unroll
@@ -84,6 +86,7 @@ __global__ __launch_bounds__(THREADS) void probe(long long *cycles, float *sink,
                 in[r] = v;
             }
         }
+      }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0;
@@ -93,7 +96,7 @@ __global__ __launch_bounds__(THREADS) void probe(long long *cycles, float *sink,
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * (THREADS / 64) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
-template <int MODE, int THREADS>
+template <int MODE, int THREADS, int UNROLL = 1>
 void run(const char *label, int instrs) {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
@@ -106,12 +109,12 @@ void run(const char *label, int instrs) {
         float *ds;
         hipMalloc(&dc, sizeof(long long) * waves);
         hipMalloc(&ds, 8);
-        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((probe<MODE, THREADS>), dim3(blocks), dim3(THREADS), 0, 0, dc, ds, 0.25f, 0.5f, 0.25f);
+        for (int w = 0; w < 3; ++w) hipLaunchKernelGGL((probe<MODE, THREADS, UNROLL>), dim3(blocks), dim3(THREADS), 0, 0, dc, ds, 0.25f, 0.5f, 0.25f);
         hipDeviceSynchronize();
         std::vector<long long> h(waves);
         hipMemcpy(h.data(), dc, sizeof(long long) * waves, hipMemcpyDeviceToHost);
         std::sort(h.begin(), h.end());
-        const double cyc = (double) h[waves / 2] / ITER;
+        const double cyc = (double) h[waves / 2] / (ITER / UNROLL * UNROLL);
         printf("  %dw/SIMD %7.1f cyc/iter/wave = %5.2f SIMD-cyc/instr", wps, cyc, cyc / instrs / wps);
         hipFree(dc);
         hipFree(ds);
@@ -127,5 +130,11 @@ int main() {
     run<4, 256>("packed y / z of 2 rows", 2 * 7);
     run<0, 1024>("x-pass 4 rows + plain y / z of 2 rows", 32 + 2 * 13);
     run<1, 1024>("x-pass 4 rows + packed y / z of 2 rows", 32 + 2 * 7);
+    printf("-- the same body unrolled: does a longer instruction stream cost more per instruction? --\n");
+    run<0, 1024, 2>("plain, loop body x 2 (~0.7 KB)", 58);
+    run<0, 1024, 8>("plain, loop body x 8 (~2.8 KB)", 58);
+    run<0, 1024, 24>("plain, loop body x 24 (~8 KB)", 58);
+    run<0, 1024, 60>("plain, loop body x 60 (~20 KB)", 58);
+    run<0, 1024, 150>("plain, loop body x 150 (~50 KB)", 58);
     return 0;
 }

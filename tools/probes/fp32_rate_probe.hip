@@ -15,7 +15,7 @@ constexpr int N = 16;  // instructions per iteration, over 8 independent destina
 
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-enum Op { FMA32, FMAC32, PKFMA32, PKMUL32, FMAC_DPP_WAVE, FMAC_DPP_ROW, MUL_DPP_WAVE, MOV_DPP_WAVE, LSHL, AND, CVTPK, BFI, FMA64, PKFMA_AND_FMA, PKADD32, CVTF32, CVTF32_SDWA, PERM, FMA32_SGPR, MUL32, LSHL_OR, MOV, FMAC_AND_DPP, FMAC_AND_PK, A_FMAC_VV, B_FMAC_SV, C_MUL_V, D_MUL_S, E_FMA_SV, F_LSHL_INPLACE, G_AND_LIT, H_AND_V, I_FMAC_VDEP, J_FMAC_SDEP, K_LSHL_V, L_FMA_VVV_DEP, M_CVTPK_DEP, N_XPASS, O_ZPASS };
+enum Op { FMA32, FMAC32, PKFMA32, PKMUL32, FMAC_DPP_WAVE, FMAC_DPP_ROW, MUL_DPP_WAVE, MOV_DPP_WAVE, LSHL, AND, CVTPK, BFI, FMA64, PKFMA_AND_FMA, PKADD32, CVTF32, CVTF32_SDWA, PERM, FMA32_SGPR, MUL32, LSHL_OR, MOV, FMAC_AND_DPP, FMAC_AND_PK, A_FMAC_VV, B_FMAC_SV, C_MUL_V, D_MUL_S, E_FMA_SV, F_LSHL_INPLACE, G_AND_LIT, H_AND_V, I_FMAC_VDEP, J_FMAC_SDEP, K_LSHL_V, L_FMA_VVV_DEP, M_CVTPK_DEP, N_XPASS, O_ZPASS, P_FMA64_S, Q_FMA64_VDEP, R_ADD64, S_MUL64_S, T_FMA64_SDEP, U_ADD64_DEP };
 
 template <int OP>
 __global__ __launch_bounds__(256) void probe(long long *cycles, float *sink, float a, float b) {
@@ -121,6 +121,12 @@ __global__ __launch_bounds__(256) void probe(long long *cycles, float *sink, flo
                                  : [u0] "v"(f[(v + 4) & 7]), [u1] "v"(f[(v + 5) & 7]), [a0] "s"(a), [a1] "s"(b), [a2] "s"(a));
                 }
             }
+            if constexpr (OP == P_FMA64_S) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(d[k]) : "s"(da), "v"(db));
+            if constexpr (OP == Q_FMA64_VDEP) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(d[k]) : "v"(da), "v"(d[k1]));
+            if constexpr (OP == T_FMA64_SDEP) asm volatile("v_fma_f64 %0, %1, %2, %0" : "+v"(d[k]) : "s"(da), "v"(d[k1]));
+            if constexpr (OP == R_ADD64) asm volatile("v_add_f64 %0, %1, %0" : "+v"(d[k]) : "v"(db));
+            if constexpr (OP == U_ADD64_DEP) asm volatile("v_add_f64 %0, %1, %2" : "=v"(d[k]) : "v"(d[k1]), "v"(d[(v + 2) & 7]));
+            if constexpr (OP == S_MUL64_S) asm volatile("v_mul_f64 %0, %1, %0" : "+v"(d[k]) : "s"(da));
             if constexpr (OP == PKFMA_AND_FMA) {
                 if (v & 1)
                     asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[k]) : "v"(a2), "v"(b2));
@@ -226,6 +232,14 @@ int main() {
     run<K_LSHL_V>("v_lshlrev_b32 u <<= u[k+1]");
     run<L_FMA_VVV_DEP>("v_fma_f32 f = vA * f[k+1] + f[k+2]");
     run<M_CVTPK_DEP>("v_cvt_pk_bf16_f32 u = (f[k], f[k+1])");
+    printf("-- fp64 --\n");
+    run<FMA64>("v_fma_f64 acc += vA * vB");
+    run<P_FMA64_S>("v_fma_f64 acc += sA * vB");
+    run<Q_FMA64_VDEP>("v_fma_f64 acc += vA * d[k+1]");
+    run<T_FMA64_SDEP>("v_fma_f64 acc += sA * d[k+1]");
+    run<R_ADD64>("v_add_f64 acc += vB");
+    run<U_ADD64_DEP>("v_add_f64 d = d[k+1] + d[k+2]");
+    run<S_MUL64_S>("v_mul_f64 acc *= sA");
     printf("-- kernel sequences (cycles per 16-slot iteration / 16: x-pass = 2 rows of 8, z-pass = 2 rows of 7) --\n");
     run<N_XPASS>("x-pass rows (16 instructions)");
     run<O_ZPASS>("z-pass rows (14 instructions)");
