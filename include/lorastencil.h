@@ -368,6 +368,55 @@ int lora_run_host_multi(int shape, int dtype, const void *in, void *out, const d
                         const int *dims, int ngpus, int quiet, lora_run_info *info);
 
 /* ========================================================================================
+ * E. Two-axis block decomposition (NEW).  A Pa x Pb process grid cuts the two OUTER dimensions of the grid --
+ *    rows x columns of the 2D shapes, planes x rows (z x y) of the 3D ones -- into one block per GPU.  A block's local
+ *    array carries ghost zones of radius x applications-per-launch x E cells on every cut side; they are refreshed every E
+ *    launches in two phases (axis B: strips packed by the block-copy kernel; then axis A: whole rows / planes in place,
+ *    B-side ghost cells included, so corners need no diagonal message) over the same callback table as the slabs
+ *    (peer = ia * Pb + ib), the second phase hidden behind the next launch's interior (deferred wait).  The loop that is
+ *    distributed is the reference's time-step loop (2d/gpu.cu:544-546, 3d/gpu_star.cu:177-181); the reference itself has
+ *    no multi-GPU path.  Reference boundary; fp64, and bf16 for the 3D shapes.  N blocks == 1 GPU bit for bit.
+ * ====================================================================================== */
+typedef struct lora_block lora_block;
+typedef struct lora_block_desc {
+    int shape, dtype;          /* a 2D or 3D lora_shape; lora_dtype                                          */
+    int global_dims[3];        /* interior extents of the WHOLE grid, outermost first                         */
+    int grid[2];               /* Pa x Pb: parts of the outermost (axis A) and of the second dimension (B)    */
+    int coords[2];             /* this block: (ia, ib); its rank in the callback table is ia * Pb + ib        */
+    const double *params;      /* as lora_plan_create (NULL: the reference harness's table)                   */
+    const double *weights;     /* nullable: taps applied per sweep                                            */
+    int device;                /* HIP device the block lives on                                               */
+    int exchange_every;        /* launches between ghost-zone refreshes; 0 = 2; clipped to the thinnest block */
+    int flags;                 /* LORA_SLAB_NO_DEFER, LORA_SLAB_NO_FUSION                                     */
+    const char *options;       /* nullable "key=value,key=value": plan options                                */
+} lora_block_desc;
+typedef struct lora_block_info_t {
+    int own_begin[2], own_end[2];    /* global interior ranges of the block's own cells along axis A / B     */
+    int ghost, ghost_lo[2], ghost_hi[2];
+    int apps_per_launch, exchange_every, steps_done;
+    int local_dims[3];               /* interior extents of the local array (own + ghost cells)              */
+    long launches, exchanges;
+    size_t local_bytes;              /* bytes of one local padded buffer                                     */
+    size_t bytes_per_refresh;        /* bytes this block sends per ghost-zone refresh (both phases)          */
+} lora_block_info_t;
+/* `comm` may be NULL for a 1 x 1 grid.  Allocates the block's two local buffers, its pack strips and streams. */
+int lora_block_create(lora_block **block, const lora_block_desc *desc, const lora_slab_comm *comm);
+void lora_block_destroy(lora_block *block);
+int lora_block_info(const lora_block *block, lora_block_info_t *info);
+/* buffer 0 <- this block's cells of the padded GLOBAL host array (ghost cells and pads included), buffer 1 <- 0 */
+int lora_block_load(lora_block *block, const void *host_global_padded);
+/* `times` kernel applications (fused launches from even time levels, single sweeps otherwise); asynchronous */
+int lora_block_run(lora_block *block, int times);
+/* several blocks of ONE decomposition driven by this host thread: every exchange phase inside one group */
+int lora_block_run_many(lora_block **blocks, int n, int times);
+int lora_block_sync(lora_block *block);
+/* own cells (+ the pads at a global edge) of the current time level -> their place in the padded GLOBAL host array */
+int lora_block_store(lora_block *block, void *host_global_padded);
+void *lora_block_buffer(lora_block *block, int which);
+void *lora_block_stream(lora_block *block);
+lora_plan *lora_block_plan(lora_block *block);
+
+/* ========================================================================================
  * C. Host helpers on the path.
  * ====================================================================================== */
 /* The params tables the reference harness builds (1d/main.cu:77-78, 2d/main.cu:139-195,

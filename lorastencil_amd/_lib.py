@@ -89,6 +89,19 @@ class SlabInfo(ctypes.Structure):
 SLAB_NO_OVERLAP, SLAB_NO_DEFER, SLAB_NO_FUSION, SLAB_RING_OF_ONE, SLAB_OVERLAP = 1, 2, 4, 8, 16
 
 
+class BlockDesc(ctypes.Structure):
+    _fields_ = [("shape", ctypes.c_int), ("dtype", ctypes.c_int), ("global_dims", ctypes.c_int * 3), ("grid", ctypes.c_int * 2),
+                ("coords", ctypes.c_int * 2), ("params", _dp), ("weights", _dp), ("device", ctypes.c_int),
+                ("exchange_every", ctypes.c_int), ("flags", ctypes.c_int), ("options", ctypes.c_char_p)]
+
+
+class BlockInfo(ctypes.Structure):
+    _fields_ = [("own_begin", ctypes.c_int * 2), ("own_end", ctypes.c_int * 2), ("ghost", ctypes.c_int), ("ghost_lo", ctypes.c_int * 2),
+                ("ghost_hi", ctypes.c_int * 2), ("apps_per_launch", ctypes.c_int), ("exchange_every", ctypes.c_int),
+                ("steps_done", ctypes.c_int), ("local_dims", ctypes.c_int * 3), ("launches", ctypes.c_long),
+                ("exchanges", ctypes.c_long), ("local_bytes", ctypes.c_size_t), ("bytes_per_refresh", ctypes.c_size_t)]
+
+
 class Rng(ctypes.Structure):
     _fields_ = [("r", ctypes.c_int32 * 34), ("pos", ctypes.c_int32)]
 
@@ -144,6 +157,17 @@ SIGNATURES = {
     "lora_slab_plan": (_vp, [_vp]),
     "lora_slab_run_many": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int]),
     "lora_slab_refresh_ghosts_many": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int]),
+    "lora_block_create": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.POINTER(BlockDesc), ctypes.POINTER(SlabComm)]),
+    "lora_block_destroy": (None, [_vp]),
+    "lora_block_info": (ctypes.c_int, [_vp, ctypes.POINTER(BlockInfo)]),
+    "lora_block_load": (ctypes.c_int, [_vp, _vp]),
+    "lora_block_run": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "lora_block_run_many": (ctypes.c_int, [ctypes.POINTER(_vp), ctypes.c_int, ctypes.c_int]),
+    "lora_block_sync": (ctypes.c_int, [_vp]),
+    "lora_block_store": (ctypes.c_int, [_vp, _vp]),
+    "lora_block_buffer": (_vp, [_vp, ctypes.c_int]),
+    "lora_block_stream": (_vp, [_vp]),
+    "lora_block_plan": (_vp, [_vp]),
     "lora_run_host_multi": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _dp, ctypes.c_int, _ip, ctypes.c_int,
                                            ctypes.c_int, ctypes.POINTER(RunInfo)]),
     "lora_plan_run_profiled": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.POINTER(RunProfile)]),

@@ -387,7 +387,10 @@ void plan_refresh(Plan &p) {
         if (p.dtype == LORA_BF16 && p.tapset == TAPS3D_SEP && p.boundary == LORA_BC_REFERENCE &&
             p.variant != LORA_VARIANT_MFMA && p.lanes3 != 0 && !p.generic &&
             (p.steps_per_launch_req == 0 || p.steps_per_launch_req == 4))
-            blanes = (p.steps_per_launch_req == 4 || p.lanes3 == 1 || npts >= 2.0e7) && prepare_3d_bf16_lanes(p);
+            // (GStencils/s per launch, this kernel / the two-sweep tile kernel, tools/bf16_crossover.py,
+            // profiles/r04_bf16_lanes_crossover.jsonl: 192^3 395 / 501, 256^3 891 / 788, 320^3 1487 / 1104, 512^3 1795 / 1345,
+            // 48 x 768^2 1243 / 1123, 96 x 768^2 1561 / 1397, 768^3 2090 / 1662)
+            blanes = (p.steps_per_launch_req == 4 || p.lanes3 == 1 || npts >= 1.2e7) && prepare_3d_bf16_lanes(p);
         if (blanes) {
             p.lanes3_active = 1;
             p.steps_per_launch = 4;

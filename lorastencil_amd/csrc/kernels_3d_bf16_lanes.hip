@@ -464,7 +464,7 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
                 static_assert(R == 4, "rows 1 and 2 are the two inner rows");
                 unsigned v1, v2;
                 yz_rows2(t[0], t[1], t[2], t[1], t[2], t[3], T, acc[l][P][1], acc[l][Q][1], acc[l][P][2], acc[l][Q][2], v1, v2);
-                if (l == K - 1) {
+                if constexpr (l == K - 1) {
                     outp[1] = v1;
                     outp[2] = v2;
                 } else {
@@ -499,7 +499,7 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
             constexpr int l = decltype(level_tag)::value;
             unsigned v0, v3;
             yz_edges(q.vu, q.t0, tk[l][0], q.vd, tk[l][1], T, acc[l][P][0], acc[l][Q][0], acc[l][P][R - 1], acc[l][Q][R - 1], v0, v3);
-            if (l == K - 1) {
+            if constexpr (l == K - 1) {
                 outp[0] = v0;
                 outp[R - 1] = v3;
             } else {

@@ -35,7 +35,11 @@ static void run(int h, int m, int n, int zc) {
     unsigned short *b0, *b1;
     if (hipMalloc(&b0, count * 2) != hipSuccess || hipMalloc(&b1, count * 2) != hipSuccess) exit(1);
     std::vector<unsigned short> hb(count);
-    for (size_t i = 0; i < count; ++i) hb[i] = (unsigned short) (0x3f00 + (i * 2654435761u) % 0x100);  // 0.5 .. 1.0
+    const bool wide = getenv("LORA_BL_WIDE_DATA") != nullptr;  // values of both signs over many binades instead of 0.5 .. 1.0
+    for (size_t i = 0; i < count; ++i) {
+        const unsigned r = (unsigned) (i * 2654435761u) ^ (unsigned) (i >> 7) * 40503u;
+        hb[i] = wide ? (unsigned short) (((r >> 3) & 0x8000) | (0x3a00 + (r % 0x600))) : (unsigned short) (0x3f00 + r % 0x100);
+    }
     hipMemcpy(b0, hb.data(), count * 2, hipMemcpyHostToDevice);
     hipMemset(b1, 0, count * 2);
 #if LORA_BL_STAMP
