@@ -37,8 +37,15 @@ def O():
 
 
 def rel_err(got, exp):
+    """Point-wise relative error with an absolute floor: |got - exp| / max(|exp|, 1e-2 x the largest |exp|).  (A plain
+    max-norm ratio lets every point hide behind the largest one; the floor keeps points of signed data that cancel to
+    nearly nothing -- whose rounding error is set by the size of their addends, not of their sum -- from reading as
+    large relative errors.)"""
+    exp = np.asarray(exp, dtype=np.float64)
     scale = np.abs(exp).max()
-    return np.abs(got - exp).max() / (scale if scale > 0 else 1.0)
+    if not scale > 0:
+        return float(np.abs(got - exp).max())
+    return float((np.abs(got - exp) / np.maximum(np.abs(exp), 1e-2 * scale)).max())
 
 
 def plan_run(L, shape, a, times, weights=None, options=None, params=None):
@@ -1042,7 +1049,9 @@ def test_bf16_host_operator_and_random_taps(L, O):
     a = O.from_bf16(bits)
     ref = O.run(shape, a, 3, weights=O.effective_weights(shape) / 36.0)
     got = O.from_bf16(plan_run_bf16(L, shape, bits, 3, weights=O.effective_weights(shape) / 36.0))
-    assert rel_err(O.interior(shape, got), O.interior(shape, ref)) < 3 * 2.0 ** -8
+    # (against the largest value: three sweeps of signed data in bf16 carry an error of ~3 bf16 ulps of their ADDENDS)
+    gi, ri = O.interior(shape, got), O.interior(shape, ref)
+    assert np.abs(gi - ri).max() / np.abs(ri).max() < 3 * 2.0 ** -8
 
 
 def test_params_are_honoured_like_the_reference(L, O):
@@ -1566,8 +1575,9 @@ def test_cli_normalize_keeps_config_3_finite(L):
                                         ("box3d1r", (256, 256, 256))])
 def test_hundred_steps_on_a_large_grid_match_the_oracle(L, O, shape, dims):
     """One long run on a grid large enough to span many chunks / panels, every XCD's share and the whole default
-    schedule (2D: 24 four-application launches + 2 two-application ones; 3D: 50 two-application launches), normalised
-    taps, default options, hipGraph off -- against the oracle (all host threads) at the north star's 1e-10."""
+    schedule (2D: sixteen six-application launches of the workgroup-row kernel + one of four; 3D at 256^3: 25 four-
+    application launches of the register-resident kernel for the star and the separable box), normalised taps, default
+    options, hipGraph off -- against the oracle (all host threads) at the north star's 1e-10."""
     w = O.effective_weights(shape)
     w = w / w.sum()
     a = O.reference_input(shape, dims) if len(dims) == 2 else \
