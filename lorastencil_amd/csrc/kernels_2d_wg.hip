@@ -344,12 +344,14 @@ __global__ __launch_bounds__(256 * S, WPS) void stencil2d_wg_kernel(const ArgsWG
             group(7 * g, std::true_type{});
         }
     };
-    static_assert(S >= 1 && S <= 3, "stages");
+    static_assert(S >= 1 && S <= 4, "stages");
     if (stage == 0) run_stage(std::integral_constant<int, 0>{});
     if constexpr (S >= 2)
         if (stage == 1) run_stage(std::integral_constant<int, 1>{});
     if constexpr (S >= 3)
         if (stage == 2) run_stage(std::integral_constant<int, 2>{});
+    if constexpr (S >= 4)
+        if (stage == 3) run_stage(std::integral_constant<int, 3>{});
 #ifdef LORA_DIAGNOSTICS
     if (a.stamps && threadIdx.x == 0) a.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -454,12 +456,15 @@ hipError_t launch_wg_t(const Plan &p, ArgsWG a, int rows_total, hipStream_t s) {
 #ifndef LORA_WG_K
 #define LORA_WG_K 6
 #endif
+#ifndef LORA_WG_S  // stages: 2 (two 8-wave workgroups per CU) for K <= 6; 4 (one 16-wave workgroup per CU) for K = 12 and 8
+#define LORA_WG_S 2
+#endif
 template <int EVAL>
 hipError_t launch_wg_e(const Plan &p, const ArgsWG &a, int rows_total, hipStream_t s) {
 #if LORA_WG_K <= 4  // the Dirichlet option: halo values at every level (K = 6 would need 98 KB of LDS per workgroup)
     if (p.boundary == LORA_BC_DIRICHLET) return launch_wg_t<EVAL, LORA_WG_K / 2, 2, 3, 4, true>(p, a, rows_total, s);
 #endif
-    return launch_wg_t<EVAL, LORA_WG_K / 2, 2, 3, 4, false>(p, a, rows_total, s);
+    return launch_wg_t<EVAL, LORA_WG_K / LORA_WG_S, LORA_WG_S, 3, 4, false>(p, a, rows_total, s);
 }
 
 }  // namespace

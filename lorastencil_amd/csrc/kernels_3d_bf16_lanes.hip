@@ -266,7 +266,7 @@ __device__ __forceinline__ f2 ypart(const f2 tm, const f2 t0, const TapsV &T) {
 // plane level L - 1 completed in the step before and completes its own plane zin - 2 L + 1; level K is the output: plane
 // k0 + p - 3 K + 1, stored at the start of step p + 1.
 template <int K, int NW>
-__global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const ArgsBL a, const TapsSep W) {
+__global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const ArgsBL a, const TapsSep W) {
     constexpr int R = 4;            // rows of a lane = rows of one LDS-DMA piece (4 x 256 bytes)
     constexpr int TH = R * NW;      // rows of a tile
     constexpr int OH = TH - 2 * K;  // output rows of a tile
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
     };
     issue_plane(0, 0);
     // LDS byte address of this lane's dword of its wave's piece in slot 0 (slot 1: + 16 KB, row r: + 256 bytes)
-    static_assert(sizeof(ring[0]) == 64 * 256, "the slot stride is 64 x 256 bytes: ds_read2st64_b32 offsets");
+    static_assert(sizeof(ring[0]) == NW * 4 * 256, "the slot stride in units of 256 bytes: ds_read2st64_b32 offsets");
     const unsigned ring_addr = (unsigned) (size_t) (__attribute__((address_space(3))) void *) &ring[0][wv][0][lane];
     // The nine taps live in VECTOR registers: on gfx950 an fp32 multiply-add with a scalar (constant-bus) operand issues at
     // HALF the rate of the all-VGPR form -- v_fmac_f32 acc += s * v: 2.9 cycles of SIMD time per wave instruction at four
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(NW * 64) void stencil3d_bf16_lanes_kernel(const Arg
                              "ds_read2st64_b32 %1, %2 offset0:%5 offset1:%6\n\t"
                              "s_waitcnt lgkmcnt(0)"
                              : "=&v"(lo), "=&v"(hi)
-                             : "v"(ring_addr), "n"(P * 64), "n"(P * 64 + 1), "n"(P * 64 + 2), "n"(P * 64 + 3)
+                             : "v"(ring_addr), "n"(P * NW * 4), "n"(P * NW * 4 + 1), "n"(P * NW * 4 + 2), "n"(P * NW * 4 + 3)
                              : "memory");
                 raw[0] = lo.x;
                 raw[1] = lo.y;
@@ -699,8 +699,13 @@ hipError_t launch_t(const Plan &p, const void *in, void *out, int begin, int end
 // K = 4 (or 2) applications in one launch over interior planes [begin, end); exactly separable box taps, reference boundary
 hipError_t launch_3d_bf16_lanes(const Plan &p, int K, const void *in, void *out, int begin, int end, hipStream_t s) {
     if (p.boundary != LORA_BC_REFERENCE || p.dtype != LORA_BF16 || p.tapset != TAPS3D_SEP) return hipErrorNotSupported;
+#ifdef LORA_BL_NW  // (tools/probes/bf16_lanes_ablate.hip: another workgroup size)
+    if (K == 4) return launch_t<4, LORA_BL_NW>(p, in, out, begin, end, s);
+    if (K == 2) return launch_t<2, LORA_BL_NW>(p, in, out, begin, end, s);
+#else
     if (K == 4) return launch_t<4, 16>(p, in, out, begin, end, s);
     if (K == 2) return launch_t<2, 16>(p, in, out, begin, end, s);
+#endif
     return hipErrorInvalidValue;
 }
 
