@@ -415,6 +415,10 @@ int lora_block_store(lora_block *block, void *host_global_padded);
 void *lora_block_buffer(lora_block *block, int which);
 void *lora_block_stream(lora_block *block);
 lora_plan *lora_block_plan(lora_block *block);
+/* Group A's generic operator on a grid[0] x grid[1] grid of blocks, one per device of this node (RCCL from
+ * ncclCommInitAll; LORA_SLAB_LOOPBACK=1: all blocks on device 0 with the loopback exchange).  What the CLIs' --grid=AxB runs. */
+int lora_run_host_blocks(int shape, int dtype, const void *in, void *out, const double *params, int times,
+                         const int *dims, const int *grid, int quiet, lora_run_info *info);
 
 /* ========================================================================================
  * C. Host helpers on the path.

@@ -168,6 +168,8 @@ SIGNATURES = {
     "lora_block_buffer": (_vp, [_vp, ctypes.c_int]),
     "lora_block_stream": (_vp, [_vp]),
     "lora_block_plan": (_vp, [_vp]),
+    "lora_run_host_blocks": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _dp, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                            ctypes.POINTER(ctypes.c_int), ctypes.c_int, _vp]),
     "lora_run_host_multi": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, _vp, _vp, _dp, ctypes.c_int, _ip, ctypes.c_int,
                                            ctypes.c_int, ctypes.POINTER(RunInfo)]),
     "lora_plan_run_profiled": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp, ctypes.POINTER(RunProfile)]),

@@ -107,3 +107,23 @@ class BlockGrid:
     def close(self) -> None:
         for b in self.blocks:
             b.close()
+
+
+def run_host_blocks(shape, a: np.ndarray, grid: Sequence[int], times: int, dtype="f64", params=None):
+    """lora_run_host_blocks: the host-buffer operator on a grid[0] x grid[1] grid of blocks (one per device; all on device 0
+    under LORA_SLAB_LOOPBACK=1).  Returns (out, lora_run_info)."""
+    sid = ops.shape_id(shape)
+    a = np.ascontiguousarray(a)
+    out = np.zeros_like(a)
+    nd = ops.ndim(shape)
+    halo = ops.halo(shape)
+    dims = (ctypes.c_int * 3)(*[a.shape[k] - 2 * halo[k] for k in range(nd)] + [0] * (3 - nd))
+    g = (ctypes.c_int * 2)(int(grid[0]), int(grid[1]))
+    info = _lib.RunInfo()
+    pp = None
+    if params is not None:
+        p = np.ascontiguousarray(params, dtype=np.float64)
+        pp = p.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    _lib.check(_lib.lib().lora_run_host_blocks(sid, ops.dtype_id(dtype), a.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), pp,
+                                              int(times), dims, g, 1, ctypes.byref(info)), "lora_run_host_blocks")
+    return out, info

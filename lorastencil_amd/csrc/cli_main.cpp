@@ -12,6 +12,7 @@
 //   --normalize                         taps / sum(taps): stays finite for any step count (box2d3r x200 overflows
 //                                       fp64 with the reference's integer taps); not reference behaviour
 //   --gpus=N           cut the grid into N slabs, one per GPU of this node, with RCCL ghost-zone exchange
+//   --grid=AxB         (2D, 3D) cut the two outer dimensions into A x B blocks instead, one per GPU (csrc/blocks.cpp)
 //                      (lora_run_host_multi; the reference is single-GPU)
 //   --dtype=bf16       (lorastencil_3d only) store the grid in bf16, accumulate in fp32 (BASELINE config 5; new)
 #include <cstdio>
@@ -129,6 +130,7 @@ int main(int argc, char *argv[]) {
     bool check = false, extra = true, bf16 = false, custom_bc = false, normalize = false;
     Fill fill = Fill::Random;
     int gpus = 1;
+    int grid[2] = {0, 0};
     for (int i = kDim + 3; i < argc; ++i) {
         const std::string a = argv[i];
         if (a == "--check")
@@ -159,6 +161,19 @@ int main(int argc, char *argv[]) {
             }
             if (gpus < 1) {
                 std::cerr << "Invalid argument: --gpus=N needs a positive integer.\n";
+                return 1;
+            }
+        }
+        else if (a.rfind("--grid=", 0) == 0 && kDim >= 2) {
+            const size_t x = a.find('x', 7);
+            try {
+                grid[0] = x == std::string::npos ? 0 : std::stoi(a.substr(7, x - 7));
+                grid[1] = x == std::string::npos ? 0 : std::stoi(a.substr(x + 1));
+            } catch (const std::exception &) {
+                grid[0] = grid[1] = 0;
+            }
+            if (grid[0] < 1 || grid[1] < 1) {
+                std::cerr << "Invalid argument: --grid=AxB needs two positive integers.\n";
                 return 1;
             }
         }
@@ -206,19 +221,28 @@ int main(int argc, char *argv[]) {
         std::cout << argv[1] << std::endl;
     }
 
-    if (gpus > 1 && !bf16) {
-        // N slabs, one per GPU; prints the reference's three lines like the single-GPU operator
-        const int rc = lora_run_host_multi(shape, LORA_F64, matrix.data(), output.data(), params, times, dims, gpus, 0, nullptr);
+    if (grid[0] > 0 && custom_bc) {
+        std::cerr << "--grid=AxB takes the reference boundary\n";
+        return 1;
+    }
+    if ((gpus > 1 || grid[0] > 0) && !bf16) {
+        // N slabs (or A x B blocks), one per GPU; prints the reference's three lines like the single-GPU operator
+        const int rc = grid[0] > 0 ? lora_run_host_blocks(shape, LORA_F64, matrix.data(), output.data(), params, times, dims, grid, 0, nullptr)
+                                   : lora_run_host_multi(shape, LORA_F64, matrix.data(), output.data(), params, times, dims, gpus, 0, nullptr);
         if (rc != LORA_OK) {
             std::printf("LoRAStencil HIP Error: %s %s\n", lora_strerror(rc), lora_last_error());
             return 1;
         }
-        if (extra) std::printf("GPUs = %d (row / plane slabs, RCCL ghost-zone exchange)\n", gpus);
+        if (extra && grid[0] > 0)
+            std::printf("GPUs = %d (%d x %d blocks of the two outer dimensions, RCCL ghost-zone exchange)\n", grid[0] * grid[1], grid[0], grid[1]);
+        else if (extra)
+            std::printf("GPUs = %d (row / plane slabs, RCCL ghost-zone exchange)\n", gpus);
     } else if (bf16) {
         // values 0..99 are exact in bf16; the operator prints the reference's three lines itself
         std::vector<uint16_t> in16(count), out16(count, 0);
         lora_f64_to_bf16(matrix.data(), in16.data(), count);
-        const int rc = gpus > 1 ? lora_run_host_multi(shape, LORA_BF16, in16.data(), out16.data(), params, times, dims,
+        const int rc = grid[0] > 0 ? lora_run_host_blocks(shape, LORA_BF16, in16.data(), out16.data(), params, times, dims, grid, 0, nullptr)
+                       : gpus > 1 ? lora_run_host_multi(shape, LORA_BF16, in16.data(), out16.data(), params, times, dims,
                                                       gpus, 0, nullptr)
                                 : lora_run_host_dtype(shape, LORA_BF16, in16.data(), out16.data(), params, times, dims, 0, nullptr);
         if (rc != LORA_OK) {

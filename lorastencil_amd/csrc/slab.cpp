@@ -853,4 +853,107 @@ int lora_run_host_multi(int shape, int dtype, const void *in, void *out, const d
     return LORA_OK;
 }
 
+// The same operator on a Pa x Pb grid of blocks (group E), one block per device of this node.  LORA_SLAB_LOOPBACK=1: all
+// blocks on device 0 with the loopback exchange (one-GPU rehearsal).  Reference boundary.
+int lora_run_host_blocks(int shape, int dtype, const void *in, void *out, const double *params, int times, const int *dims,
+                         const int *grid, int quiet, lora_run_info *info) {
+    if (!in || !out || !dims || !grid || times < 0 || grid[0] < 1 || grid[1] < 1) return LORA_EINVAL;
+    const int n = grid[0] * grid[1];
+    const int nd = lora_shape_ndim(shape);
+    if (nd != 2 && nd != 3) return LORA_EUNSUPPORTED;
+    const int ndev = lora_device_count();
+    if (ndev <= 0) {
+        lora::set_last_error_text("no HIP device visible");
+        return LORA_ENODEVICE;
+    }
+    const char *lb = std::getenv("LORA_SLAB_LOOPBACK");
+    const bool loopback = lb && lb[0] == '1';
+    if (!loopback && n > ndev) {
+        lora::set_last_error_text("more GPUs requested than this node has");
+        return LORA_EINVAL;
+    }
+    std::vector<lora_slab_comm> comms(n);
+    std::vector<void *> nccl(n, nullptr);
+    std::vector<lora_block *> blocks(n, nullptr);
+    struct Cleanup {
+        std::vector<lora_block *> &b;
+        std::vector<void *> &c;
+        ~Cleanup() {
+            for (lora_block *x : b) lora_block_destroy(x);
+            for (void *x : c)
+                if (x) (void) rccl().CommDestroy(x);
+        }
+    } cleanup{blocks, nccl};
+    if (n > 1) {
+        if (loopback) {
+            if (int rc = lora_slab_comm_loopback(comms.data(), n)) return rc;
+        } else {
+            if (!rccl().ok) {
+                lora::set_last_error_text("librccl.so could not be loaded");
+                return LORA_EUNSUPPORTED;
+            }
+            std::vector<int> devs(n);
+            for (int i = 0; i < n; ++i) devs[i] = i;
+            const int rc = rccl().CommInitAll(nccl.data(), n, devs.data());
+            if (rc) return rccl_fail("ncclCommInitAll", rc);
+            for (int i = 0; i < n; ++i)
+                if (int r2 = lora_slab_comm_rccl(&comms[i], nccl[i])) return r2;
+        }
+    }
+    lora_block_desc d{};
+    d.shape = shape;
+    d.dtype = dtype;
+    for (int k = 0; k < nd; ++k) d.global_dims[k] = dims[k];
+    d.grid[0] = grid[0];
+    d.grid[1] = grid[1];
+    d.params = params;
+    using clock = std::chrono::steady_clock;
+    const auto t_total0 = clock::now();
+    for (int r = 0; r < n; ++r) {
+        d.coords[0] = r / grid[1];
+        d.coords[1] = r % grid[1];
+        d.device = loopback ? 0 : r;
+        if (int rc = lora_block_create(&blocks[r], &d, n > 1 ? &comms[r] : nullptr)) return rc;
+        if (int rc = lora_block_load(blocks[r], in)) return rc;
+    }
+    if (times > 0) {  // warm-up outside the timed region, then the input again
+        if (int rc = lora_block_run_many(blocks.data(), n, 1)) return rc;
+        for (int r = 0; r < n; ++r) {
+            if (int rc = lora_block_sync(blocks[r])) return rc;
+            if (int rc = lora_block_load(blocks[r], in)) return rc;
+        }
+    }
+    const auto t0 = clock::now();
+    if (int rc = lora_block_run_many(blocks.data(), n, times)) return rc;
+    for (int r = 0; r < n; ++r)
+        if (int rc = lora_block_sync(blocks[r])) return rc;
+    const auto t1 = clock::now();
+    for (int r = 0; r < n; ++r)
+        if (int rc = lora_block_store(blocks[r], out)) return rc;
+    const auto t_total1 = clock::now();
+    double points = 1.0;
+    for (int k = 0; k < nd; ++k) points *= dims[k];
+    const size_t esize = dtype == LORA_BF16 ? 2 : 8;
+    lora_run_info ri{};
+    ri.sweep_seconds = std::chrono::duration<double>(t1 - t0).count();
+    ri.total_seconds = std::chrono::duration<double>(t_total1 - t_total0).count();
+    ri.gstencils = points * times / ri.sweep_seconds / 1e9;
+    ri.gstencils_refconv = ri.gstencils * lora_shape_gstencil_factor(shape);
+    ri.hbm_gbs = points * times * 2.0 * esize / ri.sweep_seconds / 1e9;
+    ri.variant = LORA_VARIANT_DIRECT;
+    lora_block_info_t bi;
+    (void) lora_block_info(blocks[0], &bi);
+    ri.steps_per_launch = bi.apps_per_launch;
+    lora::set_last_run_info(ri);
+    if (info) *info = ri;
+    if (!quiet) {
+        const long long us = std::chrono::duration_cast<std::chrono::microseconds>(t1 - t0).count();
+        std::printf("%s\n", lora::run_label(shape));
+        std::printf("Time = %lld[ms]\n", (long long) std::chrono::duration_cast<std::chrono::milliseconds>(t1 - t0).count());
+        std::printf("GStencil/s = %f\n", points * times * lora_shape_gstencil_factor(shape) / (us / 1e6) / 1e9);
+        std::fflush(stdout);
+    }
+    return LORA_OK;
+}
+
 }  // extern "C"

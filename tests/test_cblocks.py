@@ -1,9 +1,12 @@
 """The C++ two-axis block driver (csrc/blocks.cpp, include/lorastencil.h group E) against the oracle: Pa x Pb blocks in one
 process on one device (loopback exchange) == the undivided grid, bit for bit -- 2D shapes (rows x columns) and 3D shapes
 (planes x rows), fp64 and bf16, fused launches with their tails, every refresh interval, resumed runs."""
+import os
+import subprocess
+
 import numpy as np
 import pytest
-from conftest import has_gpu
+from conftest import ROOT, has_gpu
 
 
 @pytest.fixture(scope="module")
@@ -102,3 +105,32 @@ def test_loopback_blocks_bf16(L):
         out = g.store(np.zeros_like(bits))
         assert np.array_equal(out, O.run_bf16(shape, bits, 11, weights=w)), (grid, every, opts)
         g.close()
+
+
+@pytest.mark.gpu
+def test_cli_grid_flag_over_loopback(L):
+    """`lorastencil_3d star3d1r 48 40 128 6 --grid=2x2` / `lorastencil_2d ... --grid=2x3`: the reference's surface on a grid of
+    blocks (LORA_SLAB_LOOPBACK=1: all blocks on this one GPU); the same stdout lines, the same result as one GPU."""
+    from lorastencil_amd import cblocks
+    from oracle import oracle as O
+
+    env = dict(os.environ, LORA_SLAB_LOOPBACK="1")
+    for dim, argv, label in ((3, ["star3d1r", "48", "40", "128", "6", "--grid=2x2"], "GPUs = 4 (2 x 2 blocks of the two outer dimensions, RCCL ghost-zone exchange)"),
+                             (2, ["star2d1r", "384", "512", "7", "--grid=2x3"], "GPUs = 6 (2 x 3 blocks of the two outer dimensions, RCCL ghost-zone exchange)")):
+        exe = os.path.join(ROOT, "lorastencil_amd", "bin", f"lorastencil_{dim}d")
+        p = subprocess.run([exe, *argv], capture_output=True, text=True, env=env, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        lines = p.stdout.splitlines()
+        assert any(l.startswith("GStencil/s = ") for l in lines) and label in lines, p.stdout
+    p = subprocess.run([exe, "star2d1r", "384", "512", "7", "--grid=8x9"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 1 and "more GPUs requested" in p.stdout
+    os.environ["LORA_SLAB_LOOPBACK"] = "1"
+    try:
+        a = O.reference_input("star3d1r", (48, 40, 128))
+        out, info = cblocks.run_host_blocks("star3d1r", a, (2, 2), times=6)
+        assert np.array_equal(out, O.run("star3d1r", a, 6))
+        bits = O.to_bf16(O.reference_input("box3d1r", (24, 20, 64)))
+        out16, _ = cblocks.run_host_blocks("box3d1r", bits, (2, 2), times=4, dtype="bf16")
+        assert np.array_equal(out16, O.run_bf16("box3d1r", bits, 4))
+    finally:
+        del os.environ["LORA_SLAB_LOOPBACK"]
