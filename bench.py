@@ -177,17 +177,14 @@ def self_launch(args) -> int:
 
 
 def planned_launches(ndim, times, spl, fused_ok=True):
-    """(K-application launches, two-application launches, single sweeps) of one SLAB run (world > 1): the rule of
-    SlabDriver.run / lora_slab_run_many -- a fused launch of the driver's K applications whenever the time level is even
-    and K steps remain, then (2D, K >= 4) two-application launches, then single sweeps.  Fused launches all start from
-    level 0 of a run, so every one of them is at an even level.  (The single-GPU schedule, with its scratch-grid routing,
-    is reported by lora_plan_run_profiled itself.)"""
-    if spl < 2 or not fused_ok:
-        return 0, 0, times
-    nk = times // spl
-    rem = times - spl * nk
-    n2 = rem // 2 if (ndim == 2 and spl >= 4) else 0
-    return nk, n2, rem - 2 * n2
+    """(K-application launches, tail launches, single sweeps) of one SLAB run (world > 1), counted from the drivers' own
+    rule (lorastencil_amd.slab.launch_depths, which SlabDriver.run and BlockDriver.run execute and slab.cpp / blocks.cpp
+    restate).  (The single-GPU schedule, with its scratch-grid routing, is reported by lora_plan_run_profiled itself.)"""
+    from lorastencil_amd.slab import launch_depths
+    depths = launch_depths(ndim, spl, times, fused=fused_ok and spl >= 2)
+    nk = sum(1 for d in depths if d == spl and spl > 1)
+    ns = sum(1 for d in depths if d == 1) if spl > 1 else len(depths)
+    return nk, len(depths) - nk - ns, ns
 
 
 def main():

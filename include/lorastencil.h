@@ -243,6 +243,10 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
  * is the caller's for even k and zero for odd k), any number of them. */
 int lora_plan_stepk(lora_plan *plan, const void *d_in, void *d_out, void *stream);
 int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int begin, int end, void *stream);
+/* `napps` applications in one launch: 1, the plan's own depth, or one of the shallower depths its runs use for their tails
+ * (2D workgroup-row kernel: 4 and 2 under a six-application plan; 1D: powers of two below the plan's depth; else 2).
+ * LORA_EUNSUPPORTED for a depth the plan's kernels do not have. */
+int lora_plan_stepn_region(lora_plan *plan, int napps, const void *d_in, void *d_out, int begin, int end, void *stream);
 /* Halo cells of a padded device array (every cell outside the interior, any shape / dtype of the plan): copied from
  * d_src (LORA_HALO_COPY), zeroed (LORA_HALO_ZERO) or wrapped from d_dst's own opposite interior edges
  * (LORA_HALO_WRAP, periodic; LORA_EUNSUPPORTED if an extent is smaller than its halo).  What lora_plan_run uses for

@@ -29,6 +29,7 @@ from typing import Callable, Sequence
 import numpy as np
 
 from . import _lib, ops
+from .slab import next_depth
 
 try:  # torch is plumbing: device memory, streams, torch.distributed
     import torch
@@ -109,6 +110,9 @@ class HipBlockStepper:
     def stepk(self, src, dst):
         self.plan.stepk(src.data_ptr(), dst.data_ptr(), stream=self.stream)
 
+    def stepn(self, napps: int, src, dst):
+        self.plan.stepn_region(napps, src.data_ptr(), dst.data_ptr(), 0, self.plan.dims[0], stream=self.stream)
+
     def copy_block(self, dst, dst_off: int, dst_ld: int, src, src_off: int, src_ld: int, rows: int, cols: int):
         """rows x cols elements between two strided arrays (element offsets / leading dimensions): the pack / unpack kernel"""
         _lib.check(_lib.lib().lora_copy_block_f64(dst.data_ptr() + 8 * dst_off, dst_ld, src.data_ptr() + 8 * src_off, src_ld,
@@ -160,6 +164,8 @@ class Block:
             self.stepper.stepk(src, dst)
         elif napps == 2:
             self.stepper.step2(src, dst)
+        elif napps > 1:
+            self.stepper.stepn(napps, src, dst)
         else:
             self.stepper.step(src, dst)
         self.cur = dst_i
@@ -330,20 +336,14 @@ class BlockSet:
         self.steps_done += napps
 
     def run(self, times: int) -> None:
-        """`times` applications: launches of the engine's depth at even time levels, a two-application launch for a
-        remainder >= 2, single sweeps otherwise (the slab drivers' rule)"""
+        """`times` applications: launches of the engine's depth at even time levels, then the tail launches and single
+        sweeps of the slab drivers' rule (slab.next_depth)"""
         t = 0
+        tails = (2, 4) if all(hasattr(b.stepper, "stepn") for b in self.blocks.values()) else (2,)
         while t < times:
-            even = self.steps_done % 2 == 0
-            if self.apps > 1 and even and times - t >= self.apps:
-                self._launch(self.apps)
-                t += self.apps
-            elif self.apps >= 4 and even and times - t >= 2:
-                self._launch(2)
-                t += 2
-            else:
-                self._launch(1)
-                t += 1
+            d = next_depth(2, self.apps, times - t, self.steps_done % 2 == 0, True, tails)
+            self._launch(d)
+            t += d
 
     def store(self, out: np.ndarray | None = None, dst_rank: int = 0):
         """the global padded result (own cells of every block, global-edge pads from the rim blocks); distributed: on

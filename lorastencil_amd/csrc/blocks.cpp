@@ -93,9 +93,7 @@ int own_b(const lora_block *s) { return s->b1 - s->b0; }
 
 int sweep(lora_block *s, int napps, const void *src, void *dst, int b, int e) {
     if (e <= b) return LORA_OK;
-    if (napps == 1) return lora_plan_step_region(s->plan, src, dst, b, e, s->cs);
-    if (napps == s->apps) return lora_plan_stepk_region(s->plan, src, dst, b, e, s->cs);
-    return lora_plan_step2_region(s->plan, src, dst, b, e, s->cs);
+    return lora_plan_stepn_region(s->plan, napps, src, dst, b, e, s->cs);
 }
 
 int wait_b(lora_block *s) {
@@ -514,7 +512,7 @@ int lora_block_run_many(lora_block **ss, int n, int times) {
         if (s0->fused && even && times - t >= s0->apps)
             napps = s0->apps;
         else if (s0->fused && even && s0->apps >= 4 && times - t >= 2)
-            napps = 2;
+            napps = (s0->nd == 2 && s0->apps == 6 && times - t >= 4) ? 4 : 2;  // (the slab driver's rule)
         if (int rc = launch_all(ss, n, napps)) return rc;
         t += napps;
     }

@@ -369,13 +369,20 @@ void plan_refresh(Plan &p) {
                     npts >= (p.generic ? 1.0e7 : (p.tapset == TAPS3D_STAR ? 1.0e7 : 1.4e7));
         p.lanes3_active = lanes ? 1 : 0;
         if (lanes) {
+            const int spl_before = p.steps_per_launch, stream3_before = p.stream3_active, sep_before = p.sep64_valid;
             p.steps_per_launch = 4;
             p.stream3_active = 0;
             if (p.tapset == TAPS3D_BOX) {
                 p.sep64_valid = 1;
                 for (int k = 0; k < 9; ++k) p.sep64[k] = cba64l[k];
             }
-            prepare_3d_lanes(p);
+            if (!prepare_3d_lanes(p)) {  // the device has no room for a workgroup of it: the tile kernels stay
+                lanes = false;
+                p.lanes3_active = 0;
+                p.steps_per_launch = spl_before;
+                p.stream3_active = stream3_before;
+                p.sep64_valid = sep_before;
+            }
         }
         if (p.sep64_valid && !lanes)
             for (int k = 0; k < 9; ++k) p.sep64[k] = cba64[k];
@@ -1023,6 +1030,28 @@ int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int b
 int lora_plan_stepk(lora_plan *plan, const void *d_in, void *d_out, void *stream) {
     if (!plan) return LORA_EINVAL;
     return lora_plan_stepk_region(plan, d_in, d_out, 0, plan->p.dims[0], stream);
+}
+
+// `napps` applications in one launch where the plan's kernel family has that depth: 1, the plan's own depth, or one of
+// the shallower depths its runs use for their tails (2D workgroup-row kernel: 4 and 2 under a six-application plan; 1D:
+// the powers of two below the plan's depth; otherwise 2).  What the slab / block drivers issue for the tail of a run.
+int lora_plan_stepn_region(lora_plan *plan, int napps, const void *d_in, void *d_out, int begin, int end, void *stream) {
+    if (!plan || napps < 1) return LORA_EINVAL;
+    Plan &p = plan->p;
+    if (napps == 1) return lora_plan_step_region(plan, d_in, d_out, begin, end, stream);
+    if (napps == p.steps_per_launch) return lora_plan_stepk_region(plan, d_in, d_out, begin, end, stream);
+    if (napps > p.steps_per_launch) return LORA_EUNSUPPORTED;
+    const bool wg_tail = p.ndim == 2 && p.wg_active && (napps == 4 || napps == 2);
+    const bool d1_tail = p.ndim == 1 && (napps & (napps - 1)) == 0;
+    if (wg_tail || d1_tail) {
+        const int depth = p.steps_per_launch;
+        p.steps_per_launch = napps;
+        const int rc = lora_plan_stepk_region(plan, d_in, d_out, begin, end, stream);
+        p.steps_per_launch = depth;
+        return rc;
+    }
+    if (napps == 2) return lora_plan_step2_region(plan, d_in, d_out, begin, end, stream);
+    return LORA_EUNSUPPORTED;
 }
 
 // The launches of one run, in order, on `stream` (also what gets captured into a hipGraph).

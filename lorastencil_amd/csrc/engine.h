@@ -147,7 +147,7 @@ const char *kernel_name_3d_stream(const Plan &p);
 // K = 4 (or 2) applications per launch with the levels in registers (star / exactly separable box taps, fp64, any extents)
 hipError_t launch_3d_lanes(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s);
 const char *kernel_name_3d_lanes(const Plan &p);
-void prepare_3d_lanes(const Plan &p);
+bool prepare_3d_lanes(const Plan &p);
 int stream3_slots(int K, int waves, int pipe, int requested);
 int stream3_waves(const Plan &p, int K, int pipe);
 // any size, any taps (odd innermost extents): one thread per point

@@ -15,7 +15,8 @@
 //     two edge rows each wave publishes per level (2 ds_write_b128 + 2 ds_read_b128 per wave and level instead of 4 + 18);
 //     z is streamed: per level and point two partial sums live between steps (the plane above has its dz = 0 tap, the
 //     plane at hand its dz = 0 and dz = 1 taps), the third is completed in the step and becomes the next level's input.
-//   * So K = 4 fits: 4 x 32 partial-sum registers + planes in flight = 236 VGPRs, two waves per SIMD, 64 KB of LDS.
+//   * So K = 4 fits: 4 x 32 partial-sum registers + planes in flight = 236 VGPRs, two waves per SIMD, 64 KB of the CU's
+//     160 KB of LDS (registers, not LDS, are what holds it to one 512-thread workgroup per CU).
 //     The grid is read once and written once per FOUR sweeps (4 B per point and sweep compulsory).
 //   * Per accumulator the taps arrive in the oracle's order (dz, then dy, then dx): bit-identical to four single sweeps
 //     (and to the other fused 3D kernels), also for the separable box (x-pass, y-pass, z-scatter as in planes_3d.h).
@@ -403,10 +404,11 @@ hipError_t launch_lanes_t(const Plan &p, const double *in, double *out, int begi
         int nb = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NW * 64, 0) != hipSuccess || nb < 1) {
             (void) hipGetLastError();
-            nb = 0;
+            nb = -1;  // no workgroup of this kernel is resident on this device: the plan must not choose it
         }
         per_cu[dev] = nb;
     }
+    if (per_cu[dev] < 0) return hipErrorLaunchOutOfResources;
     if (end <= begin) return hipSuccess;  // prepare_3d_lanes()
     ArgsL3 a;
     a.in = in;
@@ -474,15 +476,17 @@ hipError_t launch_3d_lanes(const Plan &p, int K, const double *in, double *out, 
     return hipErrorInvalidValue;
 }
 
-// one-time host work (kernel resolution, residency query) of the plan's instantiations; no launch
-void prepare_3d_lanes(const Plan &p) {
+// one-time host work (kernel resolution, residency query) of the plan's instantiations; no launch.  false: a device is
+// there and says no workgroup of the kernel fits it -- the plan then keeps the tile kernels (capi.cpp: plan_refresh).
+bool prepare_3d_lanes(const Plan &p) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
         (void) hipGetLastError();
-        return;
+        return true;  // no device here (a build box): plans resolve as they would on the GPU
     }
-    (void) launch_3d_lanes(p, 4, nullptr, nullptr, 0, 0, nullptr);
-    (void) launch_3d_lanes(p, 2, nullptr, nullptr, 0, 0, nullptr);
+    const hipError_t e4 = launch_3d_lanes(p, 4, nullptr, nullptr, 0, 0, nullptr);
+    const hipError_t e2 = launch_3d_lanes(p, 2, nullptr, nullptr, 0, 0, nullptr);
+    return e4 == hipSuccess && e2 == hipSuccess;
 }
 
 const char *kernel_name_3d_lanes(const Plan &) { return "stencil3d_lanes_kernel"; }

@@ -92,9 +92,7 @@ namespace {
 
 int sweep(lora_slab *s, int napps, const void *src, void *dst, int b, int e) {
     if (e <= b) return LORA_OK;
-    if (napps == 1) return lora_plan_step_region(s->plan, src, dst, b, e, s->cs);
-    if (napps == s->apps) return lora_plan_stepk_region(s->plan, src, dst, b, e, s->cs);
-    return lora_plan_step2_region(s->plan, src, dst, b, e, s->cs);
+    return lora_plan_stepn_region(s->plan, napps, src, dst, b, e, s->cs);
 }
 
 int flush(lora_slab *s) {
@@ -711,7 +709,9 @@ int lora_slab_run_many(lora_slab **ss, int n, int times) {
         if (s0->fused && even && times - t >= s0->apps)
             napps = s0->apps;
         else if (s0->fused && even && s0->nd >= 2 && s0->apps >= 4 && times - t >= 2)
-            napps = 2;
+            // the tail: four through the workgroup-row kernel where six leave four or five (the single-GPU driver's
+            // choice: 944 against 2 x 885 us per launch at 16384^2), else two
+            napps = (s0->nd == 2 && s0->apps == 6 && times - t >= 4) ? 4 : 2;
         if (int rc = launch_all(ss, n, napps)) return rc;
         t += napps;
     }

@@ -383,6 +383,11 @@ class Plan:
         check(_lib.lib().lora_plan_stepk_region(self._h, _ptr(d_in), _ptr(d_out), int(begin), int(end),
                                                 _stream(stream)), "lora_plan_stepk_region")
 
+    def stepn_region(self, napps: int, d_in, d_out, begin: int, end: int, stream=None):
+        """``napps`` applications in one launch: 1, the plan's depth, or a tail depth of its kernel family."""
+        check(_lib.lib().lora_plan_stepn_region(self._h, int(napps), _ptr(d_in), _ptr(d_out), int(begin), int(end),
+                                                _stream(stream)), "lora_plan_stepn_region")
+
     def run_profiled(self, d_buf0, d_buf1, times: int, stream=None):
         """run() with HIP events around the fused and the single-sweep launches; blocks until the run is done.
         Returns a ``_lib.RunProfile``."""

@@ -113,6 +113,40 @@ def slab_layout(shape, global_dims: Sequence[int], world_size: int, rank: int, m
     return lay
 
 
+def next_depth(ndim: int, apps: int, remaining: int, even: bool, fused: bool = True, tails=(2, 4)) -> int:
+    """Applications of the next launch of a slab / block run whose full launches fuse `apps`: the full depth at an even
+    time level while that many sweeps remain; then (2D / 3D, apps >= 4) a tail launch -- four through the workgroup-row
+    kernel where a six-application 2D run leaves four or five (944 against 2 x 885 us per launch at 16384^2), else two;
+    single sweeps otherwise.  `tails`: the tail depths the stepper has.  ONE rule for slab.py, blocks.py, bench.py; slab.cpp
+    and blocks.cpp (launch_all) state the same rule in C++."""
+    if fused and even and apps > 1 and remaining >= apps:
+        return apps
+    if fused and even and ndim >= 2 and apps >= 4 and remaining >= 2:
+        if ndim == 2 and apps == 6 and remaining >= 4 and 4 in tails:
+            return 4
+        if 2 in tails:
+            return 2
+    return 1
+
+
+def launch_depths(ndim: int, apps: int, times: int, fused: bool = True, tails=(2, 4), steps_done: int = 0) -> list:
+    """The launch depths of a whole run of `times` sweeps, in order (next_depth applied until none remain)."""
+    out, t = [], 0
+    while t < times:
+        d = next_depth(ndim, apps, times - t, (steps_done + t) % 2 == 0, fused, tails)
+        out.append(d)
+        t += d
+    return out
+
+
+def stepper_tails(stepper) -> tuple:
+    """Tail depths a stepper can launch under a deeper plan: every depth for one with stepn_region (the HIP plans), two for
+    one with step2_region only (test steppers)."""
+    if hasattr(stepper, "stepn_region"):
+        return (2, 4)
+    return (2,) if hasattr(stepper, "step2_region") else ()
+
+
 def slab_schedule(sid, global_dims, world_size, rank, ring, make_stepper, fused, exchange_every, all_agree=bool):
     """Launch depth, ghost need and refresh interval of a slab decomposition, and this rank's layout and stepper.
     Everything that fixes the exchange pattern comes from rank-independent data; `all_agree` ANDs a local verdict over
@@ -241,6 +275,10 @@ class HipStepper:
 
     def step2_region(self, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
         self.plan.step2_region(src.data_ptr(), dst.data_ptr(), begin, end, stream=self.stream)
+
+    def stepn_region(self, napps: int, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
+        """A tail launch of `napps` applications under a deeper plan (lora_plan_stepn_region)."""
+        self.plan.stepn_region(napps, src.data_ptr(), dst.data_ptr(), begin, end, stream=self.stream)
 
     def wrap(self, buf: torch.Tensor) -> None:
         """Periodic halo of the LOCAL array (lora_plan_halo, wrap mode): right along the unsplit dimensions; along
@@ -479,8 +517,8 @@ class SlabDriver:
 
     # ---- one launch (1 or 2 applications) ---------------------------------------------------------------
     def _launch(self, napps: int) -> None:
-        """One launch of `napps` applications: the driver's own fused count (stepk_region), 2 (step2_region: the tail of
-        a run whose launches fuse four) or 1 (step_region)."""
+        """One launch of `napps` applications: the driver's own fused count (stepk_region), a tail depth of a run whose
+        launches fuse four or six (stepn_region / step2_region: next_depth) or 1 (step_region)."""
         lay = self.layout
         fused = napps > 1
         apps = napps
@@ -489,7 +527,14 @@ class SlabDriver:
         src, dst = self.buf[src_i], self.buf[dst_i]
         if fused and napps == self.apps:
             sweep = getattr(self.stepper, "stepk_region", None) or self.stepper.step2_region
+        elif fused and hasattr(self.stepper, "stepn_region"):
+            stepn = self.stepper.stepn_region
+
+            def sweep(a, b, lo, hi):
+                stepn(napps, a, b, lo, hi)
         elif fused:
+            if napps != 2:
+                raise ValueError(f"this stepper has no launch of {napps} applications")
             sweep = self.stepper.step2_region
         else:
             sweep = self.stepper.step_region
@@ -567,16 +612,9 @@ class SlabDriver:
     def run(self, times: int) -> None:
         """`times` kernel applications (fused pairs where the shape allows, starting at even time levels)."""
         t = 0
+        tails = stepper_tails(self.stepper)
         with self._on_stream():
             while t < times:
-                even = self.steps_done % 2 == 0
-                if self.fused and even and times - t >= self.apps:
-                    self._launch(self.apps)
-                    t += self.apps
-                elif (self.fused and even and self.ndim >= 2 and self.apps >= 4 and times - t >= 2
-                      and hasattr(self.stepper, "step2_region")):
-                    self._launch(2)
-                    t += 2
-                else:
-                    self._launch(1)
-                    t += 1
+                d = next_depth(self.ndim, self.apps, times - t, self.steps_done % 2 == 0, self.fused, tails)
+                self._launch(d)
+                t += d

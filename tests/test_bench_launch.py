@@ -40,7 +40,14 @@ def test_planned_launches_follow_the_driver_rule():
     assert bench.planned_launches(2, 21, 2) == (10, 0, 1)
     assert bench.planned_launches(2, 20, 4) == (5, 0, 0)      # an odd number of fused launches is fine in a slab run
     assert bench.planned_launches(2, 23, 4) == (5, 1, 1)      # 2D, K = 4: a two-application launch for the tail
-    assert bench.planned_launches(2, 23, 6) == (3, 2, 1)
+    assert bench.planned_launches(2, 23, 6) == (3, 1, 1)      # K = 6: 18 + a four-application tail + one single sweep
+    assert bench.planned_launches(2, 21, 6) == (3, 1, 1)      # ... 18 + a two-application tail + one
+    assert bench.planned_launches(3, 23, 4) == (5, 1, 1)      # 3D, K = 4: tails of two
+    from lorastencil_amd.slab import launch_depths
+    assert launch_depths(2, 6, 23) == [6, 6, 6, 4, 1]
+    assert launch_depths(2, 6, 23, tails=(2,)) == [6, 6, 6, 2, 2, 1]   # a stepper without four-application launches
+    assert launch_depths(2, 6, 9, steps_done=1) == [1, 6, 2]            # a resumed run starts fusing at an even level
+    assert launch_depths(2, 6, 9, fused=False) == [1] * 9
     assert bench.planned_launches(3, 7, 2) == (3, 0, 1)
     assert bench.planned_launches(2, 20, 1) == (0, 0, 20)
 
