@@ -754,6 +754,9 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "fused_z_chunk")) {
         if (value < 0 || value > 4096) return LORA_EINVAL;
         p.fused_z_chunk = value;
+    } else if (!std::strcmp(key, "spans3")) {
+        if (value < -1 || value > 1) return LORA_EINVAL;
+        p.spans3 = value;
     } else {
         return LORA_EINVAL;
     }
@@ -812,6 +815,8 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.steps_per_launch;
     else if (!std::strcmp(key, "fused_z_chunk"))
         *value = p.fused_z_chunk;
+    else if (!std::strcmp(key, "spans3"))
+        *value = p.spans3;
     else if (!std::strcmp(key, "fused_pipeline"))
         *value = p.fused_pipeline;
     else if (!std::strcmp(key, "tapset"))
@@ -855,10 +860,11 @@ const char *lora_plan_kernel_signature(const lora_plan *plan) {
     else if (k == "stencil2d_mfma_kernel")
         std::snprintf(buf, sizeof buf, "rank=%d,panel=%d", p.lowrank.rank, p.panel_width);
     else if (k == "stencil3d_lanes_kernel")
-        std::snprintf(buf, sizeof buf, "taps=%d,k=%d,fzc=%d,bc=%d", p.sep64_valid ? 2 : p.tapset, p.steps_per_launch, p.fused_z_chunk,
-                      p.boundary);
+        std::snprintf(buf, sizeof buf, "taps=%d,k=%d,fzc=%d,sp=%d,bc=%d", p.sep64_valid ? 2 : p.tapset, p.steps_per_launch,
+                      p.fused_z_chunk, p.spans3, p.boundary);
     else if (k == "stencil3d_bf16_lanes_kernel")
-        std::snprintf(buf, sizeof buf, "taps=%d,k=%d,fzc=%d,bc=%d", p.tapset, p.steps_per_launch, p.fused_z_chunk, p.boundary);
+        std::snprintf(buf, sizeof buf, "taps=%d,k=%d,fzc=%d,sp=%d,bc=%d", p.tapset, p.steps_per_launch, p.fused_z_chunk, p.spans3,
+                      p.boundary);
     else if (k == "stencil3d_planes_kernel")
 {
         const int K = p.steps_per_launch, pipe = (K == 2 || p.stream3_pipe) ? 1 : 0;

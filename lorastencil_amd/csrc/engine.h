@@ -92,6 +92,7 @@ struct Plan {
     int lanes3 = -1;          // 3D fused launches through the register-resident kernels (kernels_3d_lanes.hip, fp64; kernels_3d_bf16_lanes.hip, bf16: four applications per launch): -1 by grid size, 0 never, 1 always (star / separable box taps, reference boundary)
     int lanes3_active = 0;    // resolved
     int fused_z_chunk = 0;    // 3D fused: output planes per workgroup (0 = auto: 32, shorter on small grids)
+    int spans3 = -1;          // 3D register-resident kernels: cut the (tile, plane) line into equal pieces per CU (1), equal chunks per tile (0), by region depth (-1)
     int steps_per_launch_req = 0;  // 0 = auto, 1, 2 (2D / 3D), 4 (2D row-streaming kernel), 2 / 4 / 8 (1D)
     int steps_per_launch = 1;      // resolved
     bool generic = false;  // odd innermost extent: rows are only 8-byte aligned, the tiled kernels do not apply

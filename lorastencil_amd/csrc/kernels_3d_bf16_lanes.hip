@@ -48,6 +48,7 @@
 #include <cmath>
 
 #include "device_common.h"
+#include "spans.h"
 
 // Timing experiments for tools/probes/bf16_lanes_ablate.hip (results are WRONG with bits 1 .. 16 set): 1 no barriers, 2 no
 // stores, 4 no plane loads after the first, 8 no EDGE steps, 16 only EDGE steps; 32 = the taps as scalar operands (right
@@ -92,6 +93,7 @@ struct ArgsBL {
     int z_begin, z_end;
     int zc;
     int tiles_x, tiles_y;
+    Spans sp;  // zc == 0: spans (spans.h)
 #if LORA_BL_STAMP
     long long *stamps;  // [workgroup][wave][2]: cycles of the stamped phase, steps
 #endif
@@ -283,38 +285,28 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
-    // workgroup -> (chunk, tile): the tiles on the rim of the grid first (they run the slower EDGE steps throughout)
-    const int TX = a.tiles_x, TY = a.tiles_y, chunks = (a.z_end - a.z_begin + a.zc - 1) / a.zc;
-    int chunk, tx, ty;
-    if (TX < 3 || TY < 3) {
-        const int per_chunk = TX * TY;
-        chunk = lin / per_chunk;
-        const int rem = lin - chunk * per_chunk;
-        ty = rem / TX;
-        tx = rem - ty * TX;
+    const int TX = a.tiles_x, TY = a.tiles_y;
+    // Spans (a.zc == 0, spans.h): the workgroup owns a range of the line of all (tile, plane) pairs and runs one SEGMENT per
+    // tile the range touches; chunks (option fused_z_chunk / spans3 = 0): one segment, chunk `lin / tiles` of its tile.
+    unsigned v0 = 0, v1 = 0;
+    if (a.zc == 0) span_range(a.sp, lin, v0, v1);
+    for (bool more = true, first = true; more; first = false) {
+    int tx, ty, k0, zc;
+    if (a.zc == 0) {
+        int z0;
+        const bool any = span_next(a.sp, 3 * K - 1, v0, v1, TX, TY, tx, ty, z0, zc);
+        more = v0 < v1;
+        if (!any) continue;
+        k0 = a.z_begin + z0;
     } else {
-        const int rim = 2 * TX + 2 * (TY - 2), inner = (TX - 2) * (TY - 2);
-        if (lin < rim * chunks) {
-            chunk = lin / rim;
-            const int idx = lin - chunk * rim;
-            if (idx < 2 * TX) {
-                ty = idx < TX ? 0 : TY - 1;
-                tx = idx < TX ? idx : idx - TX;
-            } else {
-                const int k = idx - 2 * TX;
-                ty = 1 + (k >> 1);
-                tx = (k & 1) ? TX - 1 : 0;
-            }
-        } else {
-            const int l2 = lin - rim * chunks;
-            chunk = l2 / inner;
-            const int idx = l2 - chunk * inner;
-            ty = 1 + idx / (TX - 2);
-            tx = 1 + idx - (ty - 1) * (TX - 2);
-        }
+        int chunk;
+        chunk_of(lin, (a.z_end - a.z_begin + a.zc - 1) / a.zc, TX, TY, chunk, tx, ty);
+        k0 = a.z_begin + chunk * a.zc;
+        zc = min(a.zc, a.z_end - k0);
+        more = false;
     }
-    const int k0 = a.z_begin + chunk * a.zc;
-    const int zc = min(a.zc, a.z_end - k0);
+    // (the segment before is done with the rows in LDS when its slowest wave is)
+    if (!first) __builtin_amdgcn_s_barrier();
     const int X0 = tx * kOutW - 4, Y0 = ty * OH - K;  // interior coordinates of the tile's first column / row
     // this lane's cells: rows Y0 + R wv + r (r = 0 .. R - 1), columns X0 + 2 lane, + 1; padded: + 2 rows, + 4 columns,
     // clamped into the padded array (clamped cells only feed cells outside the interior, which EDGE forces, or nothing)
@@ -609,13 +601,15 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
     for (; t < t1; ++t) turn(2 * t, std::true_type{});
     for (; t < t2; ++t) turn(2 * t, std::false_type{});
     for (; t < turns; ++t) turn(2 * t, std::true_type{});
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the DMA of a plane nobody reads: it must not land in a dead workgroup's LDS)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the DMA of a plane nobody reads: it must not land in a dead workgroup's LDS,
+                                                      //  nor in the ring after the first plane of the next segment)
 #if LORA_BL_STAMP
-    if (lane == 0) {
+    if (lane == 0) {  // (of the workgroup's last segment)
         a.stamps[((long) blockIdx.x * NW + wv) * 2] = stamp_sum;
         a.stamps[((long) blockIdx.x * NW + wv) * 2 + 1] = ((long long) xy_rim << 32) | stamp_n;
     }
 #endif
+    }  // segments
 }
 #undef LORA_BL_T0
 #undef LORA_BL_T1
@@ -641,7 +635,7 @@ hipError_t launch_t(const Plan &p, const void *in, void *out, int begin, int end
     }
     if (per_cu[dev] < 0) return hipErrorLaunchOutOfResources;
     if (end <= begin) return hipSuccess;  // prepare_3d_bf16_lanes()
-    ArgsBL a;
+    ArgsBL a{};
     a.in = static_cast<const u16 *>(in);
     a.out = static_cast<u16 *>(out);
     a.h = p.dims[0];
@@ -655,28 +649,21 @@ hipError_t launch_t(const Plan &p, const void *in, void *out, int begin, int end
     a.tiles_x = (a.n + kOutW - 1) / kOutW;
     a.tiles_y = (a.m + OH - 1) / OH;
     const long tiles = (long) a.tiles_x * a.tiles_y;
-    // z-chunks: a chunk runs 3 K - 1 steps beyond its own planes, so chunks should be long; but the launch should fill the
-    // CUs (one workgroup each) in whole rounds.  Same cost model as kernels_3d_lanes.hip (rounds_eff x steps per chunk).
+    // How the launch is cut along z (spans.h): chunks of option fused_z_chunk; else spans (option spans3 = 1, or by itself
+    // where they pay: spans_pay); else equal chunks by the model of rounds of workgroups.
+    const long slots = (long) std::max(per_cu[dev], 1) * cus, depth = end - begin;
+    constexpr int S = 3 * K - 1;
+    long nblocks = 0;
+    a.zc = 0;
     if (p.fused_z_chunk > 0) {
         a.zc = std::min(p.fused_z_chunk, end - begin);
     } else {
-        const long slots = (long) std::max(per_cu[dev], 1) * cus, depth = end - begin;
-        double best = 0.0;
-        long best_c = 1;
-        for (long c = 1; c <= std::max(1L, depth / (4 * K)); ++c) {
-            const long zc = (depth + c - 1) / c, wgs = tiles * ((depth + zc - 1) / zc);
-            const double x = (double) wgs / (double) slots;
-            const double whole = std::floor(x), part = x - whole;
-            const double rounds = 1.03 * whole + (part > 1e-9 ? 0.65 + 0.4 * part : 0.0);
-            const double cost = rounds * (double) (zc + 3 * K - 1);
-            if (best == 0.0 || cost < best) {
-                best = cost;
-                best_c = c;
-            }
-        }
-        a.zc = (int) ((depth + best_c - 1) / best_c);
+        const int zc_model = chunk_model(tiles, depth, S, slots, 4 * K, nullptr);
+        const bool spans = p.spans3 == 1 || (p.spans3 < 0 && spans_pay(tiles, depth, S, slots, zc_model, 2.0 * (double) a.plane * (double) depth, 256.0e6));
+        if (spans) nblocks = spans_setup(a.sp, a.tiles_x, a.tiles_y, depth, S, slots, 10, 9);
+        if (nblocks == 0) a.zc = zc_model;  // (or a line that does not fit 31 bits of cost units)
     }
-    const long nblocks = tiles * ((end - begin + a.zc - 1) / a.zc);
+    if (a.zc > 0) nblocks = tiles * ((depth + a.zc - 1) / a.zc);
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
     TapsSep w;
     for (int k = 0; k < 3; ++k) {

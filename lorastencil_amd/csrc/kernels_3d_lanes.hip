@@ -43,6 +43,7 @@
 #include <cmath>
 
 #include "device_common.h"
+#include "spans.h"
 
 // Ablation switches for tools/probes/lanes3_ablate.hip (timing only -- results are wrong with any of them set):
 // 1 no barriers, 2 no stores, 4 no plane loads after the first, 8 no cross-lane moves, 16 no EDGE steps, 32 only EDGE steps,
@@ -69,6 +70,7 @@ struct ArgsL3 {
     int z_begin, z_end;
     int zc;
     int tiles_x, tiles_y;
+    Spans sp;  // zc == 0: spans (spans.h)
 };
 
 __device__ __forceinline__ double lane_below(double v) {  // the value lane i - 1 holds (0 in lane 0)
@@ -99,39 +101,30 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lin = xcd_contiguous(blockIdx.x, gridDim.x);
-    // workgroup -> (chunk, tile): the tiles on the rim of the grid first -- they run the slower EDGE steps throughout, and
-    // with the long workgroups dispatched first the short ones even out the end of the launch
-    const int TX = a.tiles_x, TY = a.tiles_y, chunks = (a.z_end - a.z_begin + a.zc - 1) / a.zc;
-    int chunk, tx, ty;
-    if (TX < 3 || TY < 3) {
-        const int per_chunk = TX * TY;
-        chunk = lin / per_chunk;
-        const int rem = lin - chunk * per_chunk;
-        ty = rem / TX;
-        tx = rem - ty * TX;
+    const int TX = a.tiles_x, TY = a.tiles_y;
+    // Spans (a.zc == 0, spans.h): the workgroup owns a range of the line of all (tile, plane) pairs and runs one SEGMENT per
+    // tile the range touches.  Chunks: one segment, chunk `lin / tiles` of its tile -- the tiles on the rim of the grid first
+    // (they run the slower EDGE steps throughout, and with the long workgroups dispatched first the short ones even out
+    // the end of the launch).
+    unsigned v0 = 0, v1 = 0;
+    if (a.zc == 0) span_range(a.sp, lin, v0, v1);
+    for (bool more = true, first = true; more; first = false) {
+    int tx, ty, k0, zc;
+    if (a.zc == 0) {
+        int z0;
+        const bool any = span_next(a.sp, 2 * K + 1, v0, v1, TX, TY, tx, ty, z0, zc);
+        more = v0 < v1;
+        if (!any) continue;
+        k0 = a.z_begin + z0;
     } else {
-        const int rim = 2 * TX + 2 * (TY - 2), inner = (TX - 2) * (TY - 2);
-        if (lin < rim * chunks) {
-            chunk = lin / rim;
-            const int idx = lin - chunk * rim;
-            if (idx < 2 * TX) {
-                ty = idx < TX ? 0 : TY - 1;
-                tx = idx < TX ? idx : idx - TX;
-            } else {
-                const int k = idx - 2 * TX;
-                ty = 1 + (k >> 1);
-                tx = (k & 1) ? TX - 1 : 0;
-            }
-        } else {
-            const int l2 = lin - rim * chunks;
-            chunk = l2 / inner;
-            const int idx = l2 - chunk * inner;
-            ty = 1 + idx / (TX - 2);
-            tx = 1 + idx - (ty - 1) * (TX - 2);
-        }
+        int chunk;
+        chunk_of(lin, (a.z_end - a.z_begin + a.zc - 1) / a.zc, TX, TY, chunk, tx, ty);
+        k0 = a.z_begin + chunk * a.zc;
+        zc = min(a.zc, a.z_end - k0);
+        more = false;
     }
-    const int k0 = a.z_begin + chunk * a.zc;
-    const int zc = min(a.zc, a.z_end - k0);
+    // (the segment before is done with the rows in LDS when its slowest wave is)
+    if (!first) __builtin_amdgcn_s_barrier();
     const int X0 = tx * kOutW - 4, Y0 = ty * OH - K;  // interior coordinates of the tile's first column / row
     // this lane's cells: rows Y0 + 4 wv + r (r = 0 .. 3), columns X0 + 2 lane, + 1; padded: + 2 rows, + 4 columns, clamped
     // into the padded array (clamped cells only feed cells outside the interior, which EDGE forces, or nothing)
@@ -387,6 +380,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
     for (; t < t2; ++t) turn(3 * t, std::false_type{});
     for (; t < turns; ++t) turn(3 * t, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }  // segments
 }
 
 template <int TAPSET, int K, int NW>
@@ -410,7 +404,7 @@ hipError_t launch_lanes_t(const Plan &p, const double *in, double *out, int begi
     }
     if (per_cu[dev] < 0) return hipErrorLaunchOutOfResources;
     if (end <= begin) return hipSuccess;  // prepare_3d_lanes()
-    ArgsL3 a;
+    ArgsL3 a{};
     a.in = in;
     a.out = out;
     a.h = p.dims[0];
@@ -424,36 +418,21 @@ hipError_t launch_lanes_t(const Plan &p, const double *in, double *out, int begi
     a.tiles_x = (a.n + kOutW - 1) / kOutW;
     a.tiles_y = (a.m + OH - 1) / OH;
     const long tiles = (long) a.tiles_x * a.tiles_y;
-    // z-chunks.  A chunk runs 2 K + 1 steps beyond its own planes, so chunks should be long; but the launch is bound by
-    // the bytes it moves, a round of workgroups (one per CU) takes steps x ~2.4 us whatever its kernels do, and a LAST,
-    // partly filled round is cheaper than a full one only down to about two thirds of it.  Cost model fitted to a sweep
-    // of chunk lengths (star3d1r 512^3, 110 tiles on 256 CUs, gpurun_out/lanes3_zc.txt + tools/thin3d_check.py;
-    // x = workgroups / CUs, time / 2.4 us / steps per chunk): x = 0.86 -> 1.00, 1.29 -> 1.78, 1.72 -> 1.99, 2.15 -> 2.70,
-    // 2.58 -> 2.97, 3.008 -> 3.65, 3.44 -> 3.97, 3.87 -> 4.16, 4.30 -> 4.88, 5.16 -> 5.8, 6.9 -> 7.2:
-    //     rounds_eff(x) = 1.03 floor(x) + (0.65 + 0.4 frac(x) if frac(x) > 0)
-    // and the chunk count that minimises rounds_eff x (zc + 2 K + 1) wins (chunks of at least 8 K planes while the depth
-    // allows).  The first model (whole rounds, a penalty for few of them) chose 9 chunks at 512^3 where 2 are 3 % faster,
-    // and on grids of 64 .. 256 planes -- the z-slabs of a multi-GPU run -- chunkings that were 6 - 13 % off the best.
+    // How the launch is cut along z (spans.h): chunks of option fused_z_chunk; else spans (option spans3 = 1, or by itself
+    // where they pay: spans_pay); else equal chunks by the model of rounds of workgroups.
+    const long slots = (long) std::max(per_cu[dev], 1) * cus, depth = end - begin;
+    constexpr int S = 2 * K + 1;
+    long nblocks = 0;
+    a.zc = 0;
     if (p.fused_z_chunk > 0) {
         a.zc = std::min(p.fused_z_chunk, end - begin);
     } else {
-        const long slots = (long) std::max(per_cu[dev], 1) * cus, depth = end - begin;
-        double best = 0.0;
-        long best_c = 1;
-        for (long c = 1; c <= std::max(1L, depth / (8 * K)); ++c) {
-            const long zc = (depth + c - 1) / c, wgs = tiles * ((depth + zc - 1) / zc);
-            const double x = (double) wgs / (double) slots;
-            const double whole = std::floor(x), part = x - whole;
-            const double rounds = 1.03 * whole + (part > 1e-9 ? 0.65 + 0.4 * part : 0.0);
-            const double cost = rounds * (double) (zc + 2 * K + 1);
-            if (best == 0.0 || cost < best) {
-                best = cost;
-                best_c = c;
-            }
-        }
-        a.zc = (int) ((depth + best_c - 1) / best_c);
+        const int zc_model = chunk_model(tiles, depth, S, slots, 8 * K, nullptr);
+        const bool spans = p.spans3 == 1 || (p.spans3 < 0 && spans_pay(tiles, depth, S, slots, zc_model, 8.0 * (double) a.plane * (double) depth, (TAPSET == TAPS3D_SEP ? 0.0 : 300.0e6)));
+        if (spans) nblocks = spans_setup(a.sp, a.tiles_x, a.tiles_y, depth, S, slots, 10, 9);
+        if (nblocks == 0) a.zc = zc_model;  // (or a line that does not fit 31 bits of cost units)
     }
-    const long nblocks = tiles * ((end - begin + a.zc - 1) / a.zc);
+    if (a.zc > 0) nblocks = tiles * ((depth + a.zc - 1) / a.zc);
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
     Taps27 w;
     for (int k = 0; k < 27; ++k) w.w[k] = p.w[k];

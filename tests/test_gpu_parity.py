@@ -513,12 +513,14 @@ def test_3d_register_resident_kernel_equals_step_by_step(L, O, shape, dims):
     assert L.Plan(shape, dims).set_boundary("dirichlet").set_option("lanes3", 1).kernel_name != "stencil3d_lanes_kernel"
     for t in (4, 5, 6, 7, 8, 9, 12, 13):  # 12, 13: three launches of four, the last two through the scratch grid
         exp = O.run(shape, a, t)
-        for zc in (0, 3, 9, 40):
-            got = plan_run(L, shape, a, t, options={"steps_per_launch": 4, "fused_z_chunk": zc})
+        # every way a launch is cut along z: by the plan's own rule, fixed chunks, spans (spans.h: equal pieces of the line
+        # of all (tile, plane) pairs, workgroups that cross from one tile into the next), the model's chunks
+        for cut in ({}, {"fused_z_chunk": 3}, {"fused_z_chunk": 9}, {"fused_z_chunk": 40}, {"spans3": 1}, {"spans3": 0}):
+            got = plan_run(L, shape, a, t, options=dict({"steps_per_launch": 4}, **cut))
             if np.abs(exp).max() < 2.0 ** 50:
-                assert np.array_equal(got, exp), f"{shape} {dims} t={t} zc={zc}"
+                assert np.array_equal(got, exp), f"{shape} {dims} t={t} {cut}"
             else:
-                assert rel_err(got, exp) < 1e-13, f"{shape} {dims} t={t} zc={zc}"
+                assert rel_err(got, exp) < 1e-13, f"{shape} {dims} t={t} {cut}"
 
 
 @pytest.mark.parametrize("shape", ["star3d1r", "box3d1r"])
@@ -554,6 +556,13 @@ def test_3d_register_resident_kernel_real_data_and_regions(L, O, shape):
         plan.stepk_region(src, dst, b, e)
     torch.cuda.synchronize()
     assert np.array_equal(dst.cpu().numpy(), got)
+    for cut in (1, 0):  # the same regions cut into spans / into the model's chunks
+        dst[1:-1, 2:-2, 4:-4] = -3.0
+        plan.set_option("spans3", cut)
+        for b, e in ((7, 20), (20, 45), (0, 7)):
+            plan.stepk_region(src, dst, b, e)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), got), cut
     # non-separable 27 taps are not this kernel's: the plan keeps the tile / plane kernels and their two applications
     p27 = L.Plan("box3d1r", dims).set_weights(rng.random(27)).set_option("steps_per_launch", 4)
     assert p27.kernel_name != "stencil3d_lanes_kernel" and p27.get_option("steps_per_launch") == 2
@@ -968,7 +977,8 @@ def test_bf16_register_resident_kernel_equals_step_by_step(L, O, dims):
     assert plan.kernel_name == "stencil3d_bf16_lanes_kernel" and plan.get_option("steps_per_launch") == 4
     for t in (4, 5, 8, 9, 13):
         exp = O.run_bf16(shape, bits, t, weights=w)
-        for opts in ({"steps_per_launch": 4}, {"steps_per_launch": 4, "fused_z_chunk": 3}, {"lanes3": 1, "fused_z_chunk": 16}):
+        for opts in ({"steps_per_launch": 4}, {"steps_per_launch": 4, "fused_z_chunk": 3}, {"lanes3": 1, "fused_z_chunk": 16},
+                     {"steps_per_launch": 4, "spans3": 1}, {"steps_per_launch": 4, "spans3": 0}):  # (spans.h)
             assert np.array_equal(plan_run_bf16(L, shape, bits, t, weights=w, options=opts), exp), (dims, t, opts)
     # any exactly separable taps: a (x) b (x) c of random factors
     a, b, c = (rng.standard_normal(3).astype(np.float32) for _ in range(3))
