@@ -30,7 +30,8 @@
 //     (v_cvt_pk_bf16_f32) -- so a launch is bit-identical to K single sweeps.  Unpacking a level's plane for the next level
 //     is a shift and a mask per pair.
 //   * Input planes: every wave fetches its own four rows of the next plane with ONE 1 KiB LDS-DMA (16 bytes per lane,
-//     whole 256-byte row pieces) into a private two-slot ring and picks its dwords up from there -- no staging registers.
+//     whole 256-byte row pieces) into a private ring (two slots; five for K = 4, whose EDGE steps look three planes back)
+//     and picks its dwords up from there -- no staging registers.
 //     Output planes leave as dword stores through a range-checked buffer descriptor per row, issued at the START of the
 //     next step right behind the step's one s_waitcnt vmcnt(0): everything that wait covers (the DMA of this step's plane,
 //     the stores of the plane before) was issued a whole step earlier, and no count relies on the order in which loads
@@ -279,8 +280,13 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
     // NW + 1 are never written: what the top and the bottom wave read there feeds rows that are never valid).
     __shared__ __attribute__((aligned(16))) float edge_rows[K][NW + 2][2][kTileW];
     constexpr int kLevelStride = (NW + 2) * 2 * kTileW;  // floats
-    // input planes: per wave a private ring of two 1 KiB pieces (its four rows x 256 bytes of a plane)
-    __shared__ __attribute__((aligned(16))) unsigned ring[2][NW][R][kTileW / 2];
+    // input planes: per wave a private ring of 1 KiB pieces (its four rows x 256 bytes of a plane) -- the plane on its way
+    // in, the plane of the step and, for K = 4, the three before it: an EDGE step forces level-2 cells outside the interior
+    // to the input's own values of plane zin - 3, and takes them from here.  (It used to load them from memory in the
+    // middle of the step that needs them at its end: half a step is less than a round trip under load, and a rim tile's
+    // steps took 11 % longer for 4 % more instructions -- the busiest CU of a launch runs a rim chunk and an inner one.)
+    constexpr int D = K > 2 ? 5 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned ring[D][NW][R][kTileW / 2];
 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -335,10 +341,6 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
     // EDGE: which of this lane's cells are interior cells -- in x as a mask over the pair's two halves, in y per row
     const bool xy_rim = X0 < 0 || X0 + kTileW > a.n || Y0 < 0 || Y0 + TH > a.m;  // (uniform over the workgroup)
     const unsigned colmask = ((unsigned) col < (unsigned) a.n ? 0x0000ffffu : 0u) | ((unsigned) (col + 1) < (unsigned) a.n ? 0xffff0000u : 0u);
-    // byte offset of the lane's pair inside a padded row -- for the halo loads of the EDGE steps: lanes whose pair lies
-    // inside the interior in x ask for nothing unless the whole row or plane is outside
-    const unsigned ld_off = 2u * (unsigned) min(max(col + 4, 0), a.n + 6);
-    const unsigned ld_off_rim = colmask != 0xffffffffu ? ld_off : 0x80000000u;
     bool row_in[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) row_in[r] = (unsigned) (Y0 + R * wv + r) < (unsigned) a.m;
@@ -382,8 +384,10 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
         }
     };
     issue_plane(0, 0);
+    int slot = 0;  // the ring slot of the step's input plane: step p's plane lives in slot p mod D
     // LDS byte address of this lane's dword of its wave's piece in slot 0 (slot 1: + 16 KB, row r: + 256 bytes)
-    static_assert(sizeof(ring[0]) == NW * 4 * 256, "the slot stride in units of 256 bytes: ds_read2st64_b32 offsets");
+    static_assert(sizeof(ring[0]) == NW * 4 * 256, "the slot stride");
+    constexpr unsigned kSlotBytes = NW * 4 * 256;
     const unsigned ring_addr = (unsigned) (size_t) (__attribute__((address_space(3))) void *) &ring[0][wv][0][lane];
     // The nine taps live in VECTOR registers: on gfx950 an fp32 multiply-add with a scalar (constant-bus) operand issues at
     // HALF the rate of the all-VGPR form -- v_fmac_f32 acc += s * v: 2.9 cycles of SIMD time per wave instruction at four
@@ -436,12 +440,33 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
                 // step.  Plane p landed before the step's own vmcnt(0) above.
                 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
                 u32x2 lo, hi;
-                asm volatile("ds_read2st64_b32 %0, %2 offset0:%3 offset1:%4\n\t"
-                             "ds_read2st64_b32 %1, %2 offset0:%5 offset1:%6\n\t"
-                             "s_waitcnt lgkmcnt(0)"
-                             : "=&v"(lo), "=&v"(hi)
-                             : "v"(ring_addr), "n"(P * NW * 4), "n"(P * NW * 4 + 1), "n"(P * NW * 4 + 2), "n"(P * NW * 4 + 3)
-                             : "memory");
+                const unsigned cur = ring_addr + (unsigned) slot * kSlotBytes;
+                if constexpr (EDGE && K > 2) {
+                    // ... and with it the lane's dwords of input plane p - 3 (level 2 completes plane zin - 3 in this step; its
+                    // cells outside the interior take the input's values there)
+                    const int sh = slot + 2 >= D ? slot + 2 - D : slot + 2;
+                    const unsigned old = ring_addr + (unsigned) sh * kSlotBytes;
+                    u32x2 hlo, hhi;
+                    asm volatile("ds_read2st64_b32 %0, %4 offset1:1\n\t"
+                                 "ds_read2st64_b32 %1, %4 offset0:2 offset1:3\n\t"
+                                 "ds_read2st64_b32 %2, %5 offset1:1\n\t"
+                                 "ds_read2st64_b32 %3, %5 offset0:2 offset1:3\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(lo), "=&v"(hi), "=&v"(hlo), "=&v"(hhi)
+                                 : "v"(cur), "v"(old)
+                                 : "memory");
+                    hv[0] = hlo.x;
+                    hv[1] = hlo.y;
+                    hv[2] = hhi.x;
+                    hv[3] = hhi.y;
+                } else {
+                    asm volatile("ds_read2st64_b32 %0, %2 offset1:1\n\t"
+                                 "ds_read2st64_b32 %1, %2 offset0:2 offset1:3\n\t"
+                                 "s_waitcnt lgkmcnt(0)"
+                                 : "=&v"(lo), "=&v"(hi)
+                                 : "v"(cur)
+                                 : "memory");
+                }
                 raw[0] = lo.x;
                 raw[1] = lo.y;
                 raw[2] = hi.x;
@@ -532,17 +557,8 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
         // count relies on the order in which loads and stores complete.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if constexpr (!(LORA_BL_ABLATE & 2)) store_plane(p);
-        if constexpr (!(LORA_BL_ABLATE & 4)) issue_plane(p + 1, Q);
-        if constexpr (EDGE && K > 2) {
-            // level 2 completes plane zin - 3 in this step; its cells outside the interior take the input's values there
-            const int z = zin - 3;
-            const bool z_in = (unsigned) z < (unsigned) a.h;
-            const char *src = reinterpret_cast<const char *>(a.in) + (unsigned long long) (unsigned) min(max(z + 1, 0), a.h + 1) * plane_bytes;
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(src), 0, plane_bytes, 0x00020000);
-#pragma unroll
-            for (int r = 0; r < R; ++r)
-                hv[r] = __builtin_amdgcn_raw_buffer_load_b32(rs, (z_in && row_in[r]) ? ld_off_rim : ld_off, rowoff[r], 0);
-        }
+        const int slot_next = slot + 1 == D ? 0 : slot + 1;
+        if constexpr (!(LORA_BL_ABLATE & 4)) issue_plane(p + 1, slot_next);
         LORA_BL_T1(4);
         LORA_BL_T0(5);
         if constexpr (K == 4) {
@@ -580,6 +596,7 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
                 }
             }
         }
+        slot = slot_next;
         __builtin_amdgcn_sched_barrier(0);
     };
 
