@@ -52,7 +52,8 @@
 #include "spans.h"
 
 // Timing experiments for tools/probes/bf16_lanes_ablate.hip (results are WRONG with bits 1 .. 16 set): 1 no barriers, 2 no
-// stores, 4 no plane loads after the first, 8 no EDGE steps, 16 only EDGE steps; 32 = the taps as scalar operands (right
+// stores, 4 no plane loads after the first, 8 no EDGE steps, 16 only EDGE steps, 256 no FILL copy of the first / last steps
+// (right results); 32 = the taps as scalar operands (right
 // results, the form the first version of this kernel had: an fp32 instruction with a scalar operand issues at half rate)
 #ifndef LORA_BL_ABLATE
 #define LORA_BL_ABLATE 0
@@ -421,57 +422,65 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
 #define LORA_BL_T0(n)
 #define LORA_BL_T1(n)
 #endif
-    auto step = [&](const int p, auto phase_tag, auto edge_tag) {
+    auto step = [&](const int p, auto phase_tag, auto edge_tag, auto fill_tag) {
         constexpr int P = decltype(phase_tag)::value, Q = 1 - P;
         constexpr bool EDGE = decltype(edge_tag)::value;
+        // FILL: the copy of the step for a segment's first and last steps, where some levels have nothing to do yet / any
+        // more.  Level index l (levels l -> l + 1) takes in plane zin - 2 l, which feeds planes zin - 2 l - 1 .. + 1 of
+        // level l + 1; the segment needs planes k0 - (K - l - 1) .. k0 + zc - 1 + (K - l - 1) of that level: the level has
+        // work in steps 3 l .. zc + 2 K + l - 1 only.  Of a segment's zc + 3 K - 1 steps that is 6 steps' worth of
+        // arithmetic in 24 level-steps (K = 4) -- 3.6 % of a 154-plane chunk.
+        constexpr bool FILL = decltype(fill_tag)::value;
+        auto active = [&](int l) { return !FILL || (p >= 3 * l && p <= zc + 2 * K + l - 1); };
         const int zin = k0 - K + p;
         unsigned hv[R];     // EDGE: what level-2 cells outside the interior are forced to
         f2 tk[K][2];  // per level: x-passed row 1, and row R - 1's y-pass short of the lower neighbour's row
         unsigned raw[R];  // the input plane's dwords of this lane
+        auto pickup = [&]() {  // this lane's dwords of the step's input plane (and an EDGE step's halo values) out of the ring
+            // Picked up here, not at the top of the step: four registers less while the upper levels run.  Issue and wait
+            // in ONE statement: split in two (the read a level earlier, to hide its round trip) the compiler is free to
+            // copy the destination registers before the data has arrived -- wrong planes, seen.  And by hand at all:
+            // the compiler knows that the DMA writes `ring` but not WHICH slot, so a plain read of slot P waits
+            // (s_waitcnt vmcnt) for the DMA of slot Q issued a moment ago -- the whole latency of the prefetch, every
+            // step.  Plane p landed before the step's own vmcnt(0) above.
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 lo, hi;
+            const unsigned cur = ring_addr + (unsigned) slot * kSlotBytes;
+            if constexpr (EDGE && K > 2) {
+                // ... and with it the lane's dwords of input plane p - 3 (level 2 completes plane zin - 3 in this step; its
+                // cells outside the interior take the input's values there)
+                const int sh = slot + 2 >= D ? slot + 2 - D : slot + 2;
+                const unsigned old = ring_addr + (unsigned) sh * kSlotBytes;
+                u32x2 hlo, hhi;
+                asm volatile("ds_read2st64_b32 %0, %4 offset1:1\n\t"
+                             "ds_read2st64_b32 %1, %4 offset0:2 offset1:3\n\t"
+                             "ds_read2st64_b32 %2, %5 offset1:1\n\t"
+                             "ds_read2st64_b32 %3, %5 offset0:2 offset1:3\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(lo), "=&v"(hi), "=&v"(hlo), "=&v"(hhi)
+                             : "v"(cur), "v"(old)
+                             : "memory");
+                hv[0] = hlo.x;
+                hv[1] = hlo.y;
+                hv[2] = hhi.x;
+                hv[3] = hhi.y;
+            } else {
+                asm volatile("ds_read2st64_b32 %0, %2 offset1:1\n\t"
+                             "ds_read2st64_b32 %1, %2 offset0:2 offset1:3\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(lo), "=&v"(hi)
+                             : "v"(cur)
+                             : "memory");
+            }
+            raw[0] = lo.x;
+            raw[1] = lo.y;
+            raw[2] = hi.x;
+            raw[3] = hi.y;
+        };
         // level l + 1 from the plane of level l (l = 0: the input plane): everything that needs no other wave's row
         auto ahead = [&](auto level_tag) {
             constexpr int l = decltype(level_tag)::value;
-            if constexpr (l == 0) {
-                // Picked up here, not at the top of the step: four registers less while the upper levels run.  Issue and wait
-                // in ONE statement: split in two (the read a level earlier, to hide its round trip) the compiler is free to
-                // copy the destination registers before the data has arrived -- wrong planes, seen.  And by hand at all:
-                // the compiler knows that the DMA writes `ring` but not WHICH slot, so a plain read of slot P waits
-                // (s_waitcnt vmcnt) for the DMA of slot Q issued a moment ago -- the whole latency of the prefetch, every
-                // step.  Plane p landed before the step's own vmcnt(0) above.
-                typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-                u32x2 lo, hi;
-                const unsigned cur = ring_addr + (unsigned) slot * kSlotBytes;
-                if constexpr (EDGE && K > 2) {
-                    // ... and with it the lane's dwords of input plane p - 3 (level 2 completes plane zin - 3 in this step; its
-                    // cells outside the interior take the input's values there)
-                    const int sh = slot + 2 >= D ? slot + 2 - D : slot + 2;
-                    const unsigned old = ring_addr + (unsigned) sh * kSlotBytes;
-                    u32x2 hlo, hhi;
-                    asm volatile("ds_read2st64_b32 %0, %4 offset1:1\n\t"
-                                 "ds_read2st64_b32 %1, %4 offset0:2 offset1:3\n\t"
-                                 "ds_read2st64_b32 %2, %5 offset1:1\n\t"
-                                 "ds_read2st64_b32 %3, %5 offset0:2 offset1:3\n\t"
-                                 "s_waitcnt lgkmcnt(0)"
-                                 : "=&v"(lo), "=&v"(hi), "=&v"(hlo), "=&v"(hhi)
-                                 : "v"(cur), "v"(old)
-                                 : "memory");
-                    hv[0] = hlo.x;
-                    hv[1] = hlo.y;
-                    hv[2] = hhi.x;
-                    hv[3] = hhi.y;
-                } else {
-                    asm volatile("ds_read2st64_b32 %0, %2 offset1:1\n\t"
-                                 "ds_read2st64_b32 %1, %2 offset0:2 offset1:3\n\t"
-                                 "s_waitcnt lgkmcnt(0)"
-                                 : "=&v"(lo), "=&v"(hi)
-                                 : "v"(cur)
-                                 : "memory");
-                }
-                raw[0] = lo.x;
-                raw[1] = lo.y;
-                raw[2] = hi.x;
-                raw[3] = hi.y;
-            }
+            if constexpr (l == 0) pickup();
             const unsigned(&in)[R] = l == 0 ? raw : done[l];
             f2 t[R];
             xpass_rows(in, T.c0, T.c1, T.c2, t);
@@ -529,7 +538,14 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
         // with a barrier each: the x-passed rows a wave keeps for behind the barrier are then two levels' worth, not four, and
         // one copy of edge_rows serves (a half's rows are rewritten a whole step later, two barriers on).
         LORA_BL_T0(1);
-        if constexpr (K == 4) {
+        if constexpr (FILL) {  // (tests uniform over the workgroup; every wave meets the step's two barriers)
+            if constexpr (K == 4) {
+                if (active(3)) ahead(std::integral_constant<int, 3>{});
+                if (active(2)) ahead(std::integral_constant<int, 2>{});
+            } else {
+                if (active(1)) ahead(std::integral_constant<int, 1>{});
+            }
+        } else if constexpr (K == 4) {
             ahead(std::integral_constant<int, 3>{});
             ahead(std::integral_constant<int, 2>{});
         } else {
@@ -541,7 +557,14 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         LORA_BL_T1(2);
         LORA_BL_T0(3);
-        if constexpr (K == 4) {
+        if constexpr (FILL) {
+            if constexpr (K == 4) {
+                if (active(3)) behind(std::integral_constant<int, 3>{}, fetch(std::integral_constant<int, 3>{}));
+                if (active(2)) behind(std::integral_constant<int, 2>{}, fetch(std::integral_constant<int, 2>{}));
+            } else {
+                if (active(1)) behind(std::integral_constant<int, 1>{}, fetch(std::integral_constant<int, 1>{}));
+            }
+        } else if constexpr (K == 4) {
             const Rows3 q3 = fetch(std::integral_constant<int, 3>{}), q2 = fetch(std::integral_constant<int, 2>{});
             __builtin_amdgcn_sched_barrier(0);
             behind(std::integral_constant<int, 3>{}, q3);
@@ -561,7 +584,14 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
         if constexpr (!(LORA_BL_ABLATE & 4)) issue_plane(p + 1, slot_next);
         LORA_BL_T1(4);
         LORA_BL_T0(5);
-        if constexpr (K == 4) {
+        if constexpr (FILL) {
+            if constexpr (K == 4)
+                if (active(1)) ahead(std::integral_constant<int, 1>{});
+            if (active(0))
+                ahead(std::integral_constant<int, 0>{});
+            else
+                pickup();  // (the halo values the forcing below takes)
+        } else if constexpr (K == 4) {
             ahead(std::integral_constant<int, 1>{});
             ahead(std::integral_constant<int, 0>{});
         } else {
@@ -573,7 +603,11 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         LORA_BL_T1(6);
         LORA_BL_T0(7);
-        if constexpr (K == 4) {
+        if constexpr (FILL) {
+            if constexpr (K == 4)
+                if (active(1)) behind(std::integral_constant<int, 1>{}, fetch(std::integral_constant<int, 1>{}));
+            if (active(0)) behind(std::integral_constant<int, 0>{}, fetch(std::integral_constant<int, 0>{}));
+        } else if constexpr (K == 4) {
             const Rows3 q1 = fetch(std::integral_constant<int, 1>{}), q0 = fetch(std::integral_constant<int, 0>{});
             __builtin_amdgcn_sched_barrier(0);
             behind(std::integral_constant<int, 1>{}, q1);
@@ -610,14 +644,20 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
     if (LORA_BL_ABLATE & 8) p1 = 0, p2 = steps;
     if (LORA_BL_ABLATE & 16) p1 = steps;
     const int t1 = min((p1 + 1) / 2, turns), t2 = min(max(p2 / 2, t1), turns);
-    auto turn = [&](const int p, auto edge_tag) {
-        step(p, std::integral_constant<int, 0>{}, edge_tag);
-        step(p + 1, std::integral_constant<int, 1>{}, edge_tag);
+    // ... and the first 3 (K - 1) steps and the steps from zc + 2 K on run the FILL copy (an EDGE copy: forcing cells that
+    // need none changes nothing).
+    const int tf = (LORA_BL_ABLATE & 256) ? 0 : min((3 * (K - 1) + 1) / 2, turns);
+    const int td = (LORA_BL_ABLATE & 256) ? turns : max(min((zc + 2 * K) / 2, turns), tf);
+    auto turn = [&](const int p, auto edge_tag, auto fill_tag) {
+        step(p, std::integral_constant<int, 0>{}, edge_tag, fill_tag);
+        step(p + 1, std::integral_constant<int, 1>{}, edge_tag, fill_tag);
     };
     int t = 0;
-    for (; t < t1; ++t) turn(2 * t, std::true_type{});
-    for (; t < t2; ++t) turn(2 * t, std::false_type{});
-    for (; t < turns; ++t) turn(2 * t, std::true_type{});
+    for (; t < tf; ++t) turn(2 * t, std::true_type{}, std::true_type{});
+    for (; t < min(t1, td); ++t) turn(2 * t, std::true_type{}, std::false_type{});
+    for (; t < min(t2, td); ++t) turn(2 * t, std::false_type{}, std::false_type{});
+    for (; t < td; ++t) turn(2 * t, std::true_type{}, std::false_type{});
+    for (; t < turns; ++t) turn(2 * t, std::true_type{}, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the DMA of a plane nobody reads: it must not land in a dead workgroup's LDS,
                                                       //  nor in the ring after the first plane of the next segment)
 #if LORA_BL_STAMP
