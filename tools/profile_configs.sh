@@ -3,8 +3,10 @@
 # passes (fetch, write, sq1, sq2, sq3), condensed into profiles/<round>_<name>_{kernel_stats.csv,pmc.json} and the
 # profiles/pmc_traffic.json entry bench.py cites.   tools/profile_configs.sh r04    (through gpurun, from the repo root)
 round=${1:-r04}
+# PC_ONLY="star3d1r box3d1r": only these configs
 run() {
     name=$1; kernel=$2; shift 2
+    if [ -n "$PC_ONLY" ]; then case " $PC_ONLY " in *" $name "*) ;; *) return 0;; esac; fi
     tag=${round}_${name}
     tools/profile_bench.sh $tag "$@" > gpurun_out/pc_${tag}.log 2>&1
     key=$(grep '^{' gpurun_out/pk_${tag}_stats.log | tail -1 | python3 -c 'import json,sys; print(json.loads(sys.stdin.read())["roofline"]["traffic_key"])')
