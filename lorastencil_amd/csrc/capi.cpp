@@ -265,9 +265,10 @@ void plan_refresh(Plan &p) {
                 }
             }
         }
-        // 49 direct taps (no low-rank form) do not fit the scalar registers of the six-application kernel beside its
-        // three levels per wave: such plans keep four applications per launch unless six were asked for
-        if (p.steps_per_launch == 6 && p.steps_per_launch_req == 0 && p.fused_eval == TAPS2D_BOX) p.steps_per_launch = 4;
+        // (49 direct taps -- a table with no low-rank form -- do not fit the scalar registers of the six-application kernel
+        // beside its three levels per wave, and rounds 2 - 3 kept such plans at four applications per launch for it.
+        // Measured, six win all the same: 395 against 264 - 295 GStencils/s at 8192^2, 432 against 333 at 16384^2
+        // (tools/k6_general.py): the taps come from the constant cache, the bytes per sweep are a third less.)
         // which kernel family lora_plan_stepk launches: the workgroup-row kernel for six applications and, in such plans,
         // for the four- and two-application tails of a run; plans that ask for four or two keep the row-streaming kernel
         // (option wg = 1: the workgroup-row kernel at every depth)

@@ -161,11 +161,9 @@ def test_odd_innermost_extents_use_the_generic_kernels(L, O, shape, dims):
     if len(dims) == 3:
         assert "generic" in plan.kernel_name
     else:
-        # (odd extents keep the direct tap order: the 49 taps of the box then run four applications per launch)
-        if shape == "box2d3r":
-            assert plan.kernel_name == "stencil2d_stream_kernel" and plan.get_option("steps_per_launch") == 4
-        else:
-            assert plan.kernel_name == "stencil2d_wg_kernel" and plan.get_option("steps_per_launch") == 6
+        # (odd extents keep the direct tap order -- the box then evaluates its 49 taps one by one, six applications per
+        # launch all the same)
+        assert plan.kernel_name == "stencil2d_wg_kernel" and plan.get_option("steps_per_launch") == 6
         p4 = L.Plan(shape, dims).set_option("steps_per_launch", 4)
         assert p4.kernel_name == "stencil2d_stream_kernel" and p4.get_option("steps_per_launch") == 4
         assert "generic" in L.Plan(shape, dims).set_option("stream", 0).kernel_name
@@ -269,6 +267,28 @@ def test_fused_two_step_launches_equal_step_by_step(L, O, shape, dims, kernel):
             assert np.array_equal(got, exp), f"{shape} {dims} t={t}"
         else:
             assert rel_err(got, exp) < 1e-13, f"{shape} {dims} t={t}"
+
+
+@pytest.mark.parametrize("dims", [(64, 128), (90, 250), (13, 233), (150, 1430), (700, 118)])
+def test_general_49_tap_tables_run_six_applications_per_launch(L, O, dims):
+    """A 7 x 7 table with no low-rank form (the reference's gpu_box_2d3r honours all 49 params, 2d/gpu.cu:276-350): the
+    workgroup-row kernel with the taps evaluated one by one, six applications per launch by default (432 against 333
+    GStencils/s with four at 16384^2), its four / two tails and single sweeps -- exact on small integers, to rounding on
+    real data."""
+    rng = np.random.default_rng(dims[0])
+    wi = rng.integers(-2, 3, 49).astype(np.float64) / 64.0  # full rank with probability ~1: no factor form; dyadic: exact sums
+    a = np.zeros(O.padded_shape("box2d3r", dims))
+    a[...] = rng.integers(-2, 3, a.shape)
+    plan = L.Plan("box2d3r", dims).set_weights(wi)
+    assert plan.kernel_name == "stencil2d_wg_kernel" and plan.get_option("steps_per_launch") == 6
+    for t in (6, 7, 8):  # (numerators below 2^52: 49 taps of |w| <= 2 grow a sweep's values by at most 64)
+        exp = O.run("box2d3r", a, t, weights=wi)
+        assert np.array_equal(plan_run(L, "box2d3r", a, t, weights=wi), exp), (dims, t)
+    wr = rng.standard_normal(49)
+    wr /= np.abs(wr).sum()
+    b = rng.standard_normal(a.shape)
+    for t in (6, 13, 23):
+        assert rel_err(plan_run(L, "box2d3r", b, t, weights=wr), O.run("box2d3r", b, t, weights=wr)) < 1e-12, (dims, t)
 
 
 @pytest.mark.parametrize("shape,dims,times", [("star2d1r", (150, 380), 20), ("box2d3r", (70, 130), 12), ("star3d1r", (20, 24, 64), 10),
