@@ -580,9 +580,12 @@ int lora_plan_create(lora_plan **out, int shape, int dtype, const int *dims, con
     return LORA_OK;
 }
 
+static void torus_drop(lora_plan *plan);
+
 void lora_plan_destroy(lora_plan *plan) {
     if (plan && plan->graph_exec) (void) hipGraphExecDestroy(plan->graph_exec);
     if (plan && plan->scratch) (void) hipFree(plan->scratch);
+    if (plan) torus_drop(plan);
     delete plan;
 }
 
@@ -758,6 +761,8 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
     } else if (!std::strcmp(key, "spans3")) {
         if (value < -1 || value > 1) return LORA_EINVAL;
         p.spans3 = value;
+    } else if (!std::strcmp(key, "torus")) {
+        p.torus = value ? 1 : 0;
     } else {
         return LORA_EINVAL;
     }
@@ -818,6 +823,8 @@ int lora_plan_get_option(const lora_plan *plan, const char *key, int *value) {
         *value = p.fused_z_chunk;
     else if (!std::strcmp(key, "spans3"))
         *value = p.spans3;
+    else if (!std::strcmp(key, "torus"))
+        *value = p.torus;
     else if (!std::strcmp(key, "fused_pipeline"))
         *value = p.fused_pipeline;
     else if (!std::strcmp(key, "tapset"))
@@ -1206,6 +1213,143 @@ struct RunMarks {  // lora_plan_run_profiled: events around the fused and the si
     int fused_launches = 0, two_launches = 0, single_launches = 0;
 };
 
+// ---- the periodic option in fused launches: the torus by ghost zones ---------------------------------------------
+// A fused launch cannot wrap the halo of its intermediate levels, so rounds 1 - 3 ran periodic grids one sweep at a time
+// behind a halo wrap each.  What the slab drivers do for a cut serves for the torus too: extend the grid by a ghost zone
+// of radius x applications-per-launch cells on EVERY side, fill it with the periodic images of the interior, and run the
+// ordinary fused kernels on the extended grid -- ghost cells are plain interior cells of that problem, computed by the same
+// arithmetic on the same values as their originals, so after a launch of K applications everything but the outermost
+// radius x K cells is right, the true interior included; wrap the ring again, launch again.  Costs two more buffers and,
+// per launch, a wrap of the ring (surface work) and the sweeps' share of the ghost cells (16384^2, K = 6: 0.4 %).
+// Bit-identical to wrap + single sweep wherever the fused kernels are bit-identical to single sweeps.
+static int torus_radius(int nd) { return nd == 1 ? 4 : (nd == 2 ? 3 : 1); }
+static const int *torus_pads(int nd) {
+    static const int h1[1] = {4}, h2[2] = {4, 4}, h3[3] = {1, 2, 4};  // (kernels_halo.hip: launch_halo)
+    return nd == 1 ? h1 : (nd == 2 ? h2 : h3);
+}
+
+static void torus_drop(lora_plan *plan) {
+    if (plan->torus) lora_plan_destroy(plan->torus);
+    plan->torus = nullptr;
+    for (void *&b : plan->torus_buf) {
+        if (b) (void) hipFree(b);
+        b = nullptr;
+    }
+    plan->torus_bytes = 0;
+    plan->torus_tried = false;
+}
+
+// the extended plan and its buffers, built on first need; nullptr: this plan's periodic runs stay single sweeps
+static lora_plan *torus_prepare(lora_plan *plan) {
+    Plan &p = plan->p;
+    if (p.boundary != LORA_BC_PERIODIC || p.torus == 0 || p.steps_per_launch_req == 1 || p.variant != LORA_VARIANT_DIRECT) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        (void) hipGetLastError();
+        return nullptr;
+    }
+    if (plan->torus_tried && plan->torus_epoch == p.epoch && plan->torus_device == dev) return plan->torus;
+    if (plan->capturing) return nullptr;  // (no allocation inside a stream capture; lora_plan_run prepares before it)
+    torus_drop(plan);
+    plan->torus_tried = true;
+    plan->torus_epoch = p.epoch;
+    plan->torus_device = dev;
+    const int nd = p.ndim, r = torus_radius(nd), kmax = nd == 1 ? 32 : (nd == 2 ? 6 : 4);
+    const int *pad = torus_pads(nd);
+    int ext[3] = {0, 0, 0};
+    for (int d = 0; d < nd; ++d) {
+        int g = r * kmax;
+        if (d == nd - 1 && p.dtype == LORA_BF16) g = (g + 3) / 4 * 4;  // rows stay whole 8-byte units, a multiple of 8 cells
+        if (g + pad[d] > p.dims[d]) return nullptr;  // an image of an image: grids this small keep the single sweeps
+        plan->torus_ghost[d] = g;
+        ext[d] = p.dims[d] + 2 * g;
+    }
+    lora_plan *tp = nullptr;
+    if (lora_plan_create(&tp, p.shape, p.dtype, ext, nullptr) != LORA_OK) return nullptr;
+    bool ok = lora_plan_set_boundary(tp, LORA_BC_REFERENCE) == LORA_OK && lora_plan_set_weights(tp, p.w, p.ntaps) == LORA_OK;
+    if (ok && p.steps_per_launch_req > 1) (void) lora_plan_set_option(tp, "steps_per_launch", p.steps_per_launch_req);
+    ok = ok && tp->p.steps_per_launch >= 2 && tp->p.steps_per_launch <= kmax;
+    const size_t bytes = ok ? lora_plan_padded_bytes(tp) : 0;
+    for (int i = 0; ok && i < 2; ++i)
+        if (hipMalloc(&plan->torus_buf[i], bytes) != hipSuccess) {
+            (void) hipGetLastError();
+            plan->torus_buf[i] = nullptr;
+            ok = false;
+        }
+    if (!ok) {
+        lora_plan_destroy(tp);
+        for (void *&b : plan->torus_buf) {
+            if (b) (void) hipFree(b);
+            b = nullptr;
+        }
+        return nullptr;
+    }
+    plan->torus = tp;
+    plan->torus_bytes = bytes;
+    return tp;
+}
+
+constexpr int kTorusNotTaken = -1000;
+
+static int run_torus(lora_plan *plan, void *d_buf0, void *d_buf1, int times, hipStream_t s, RunMarks *marks) {
+    if (times < 2) return kTorusNotTaken;
+    lora_plan *tp = torus_prepare(plan);
+    if (!tp) return kTorusNotTaken;
+    const Plan &p = plan->p;
+    const int nd = p.ndim, K = tp->p.steps_per_launch;
+    const int *pad = torus_pads(nd);
+    int ring[3] = {0, 0, 0};
+    for (int d = 0; d < nd; ++d) ring[d] = pad[d] + plan->torus_ghost[d];
+    void *buf[2] = {d_buf0, d_buf1};
+    void *E[2] = {plan->torus_buf[0], plan->torus_buf[1]};
+    auto hip = [&](hipError_t e, const char *what) -> int {
+        if (e == hipSuccess) return LORA_OK;
+        lora::set_last_error(what, e);
+        return LORA_EHIP;
+    };
+    // level 0: the interior into the extended grid's middle, its images into everything around it
+    if (int rc = hip(lora::launch_copy_interior(p.dtype, nd, p.dims, E[0], ring, buf[0], pad, s), "torus: copy in")) return rc;
+    if (int rc = hip(lora::launch_ring_wrap(p.dtype, nd, p.dims, ring, E[0], s), "torus: wrap")) return rc;
+    int cur = 0, left = times;
+    while (left > 0) {
+        int d = 1;
+        if (left >= K)
+            d = K;
+        else if (nd == 1)
+            while (2 * d <= left && 2 * d <= K) d *= 2;
+        else if (nd == 2 && K == 6 && left >= 4)
+            d = 4;
+        else if (left >= 2)
+            d = 2;
+        int rc = lora_plan_stepn_region(tp, d, E[cur], E[1 - cur], 0, tp->p.dims[0], s);
+        while (rc == LORA_EUNSUPPORTED && d > 1) {  // (a depth this plan's kernels do not have: the next one down)
+            d = d > 2 ? 2 : 1;
+            rc = lora_plan_stepn_region(tp, d, E[cur], E[1 - cur], 0, tp->p.dims[0], s);
+        }
+        if (rc != LORA_OK) return rc;
+        if (int rc2 = hip(lora::launch_ring_wrap(p.dtype, nd, p.dims, ring, E[1 - cur], s), "torus: wrap")) return rc2;
+        if (marks) {
+            if (d == K)
+                ++marks->fused_launches;
+            else if (d > 1)
+                ++marks->two_launches;
+            else
+                ++marks->single_launches;
+        }
+        cur = 1 - cur;
+        left -= d;
+    }
+    if (marks) {
+        (void) hipEventRecord(marks->ev[1], s);
+        (void) hipEventRecord(marks->ev[2], s);
+    }
+    // the result: the extended grid's middle back into the caller's buffer, and that buffer's halo = its periodic images
+    if (int rc = hip(lora::launch_copy_interior(p.dtype, nd, p.dims, buf[times % 2], pad, E[cur], ring, s), "torus: copy out")) return rc;
+    const int rc = hip(lora::launch_halo(p, buf[times % 2], nullptr, lora::HALO_WRAP, s), "periodic halo");
+    if (marks) (void) hipEventRecord(marks->ev[3], s);
+    return rc;
+}
+
 static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream, RunMarks *marks = nullptr) {
     Plan &p = plan->p;
     void *buf[2] = {d_buf0, d_buf1};
@@ -1233,9 +1377,13 @@ static int run_launches(lora_plan *plan, void *d_buf0, void *d_buf1, int times, 
     }
 
     if (p.boundary == LORA_BC_PERIODIC) {
-        // torus: refresh the source's halo from the opposite interior edges before every sweep, and once more at the
-        // end so that the result is a consistent periodic array (single sweeps: a fused launch would need the wrap
-        // of its intermediate level)
+        // torus: fused launches on a ghost-extended grid where that applies (run_torus); else refresh the source's halo
+        // from the opposite interior edges before every sweep, and once more at the end so that the result is a
+        // consistent periodic array
+        {
+            const int rc = run_torus(plan, d_buf0, d_buf1, times, s, marks);
+            if (rc != kTorusNotTaken) return rc;
+        }
         mark(1);
         mark(2);
         for (int i = 0; i < times; ++i) {
@@ -1409,6 +1557,7 @@ int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *
         // a scratch grid, if this run's schedule wants one, is allocated BEFORE the capture (hipMalloc and the null-stream
         // memset do not belong inside one); while capturing, run_launches only uses a grid that is already there
         if (run_can_fuse(p) && !run_is_natural3(p)) (void) fused_schedule(plan, times, true);
+        if (p.boundary == LORA_BC_PERIODIC && times >= 2) (void) torus_prepare(plan);  // (likewise: the extended grid's buffers)
         hipGraph_t graph = nullptr;
         hipError_t e = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
         if (e != hipSuccess) {

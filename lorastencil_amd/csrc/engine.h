@@ -93,6 +93,7 @@ struct Plan {
     int lanes3_active = 0;    // resolved
     int fused_z_chunk = 0;    // 3D fused: output planes per workgroup (0 = auto: 32, shorter on small grids)
     int spans3 = -1;          // 3D register-resident kernels: cut the (tile, plane) line into equal pieces per CU (1), equal chunks per tile (0), by region depth (-1)
+    int torus = 1;            // periodic boundary: runs in fused launches on a ghost-extended grid (1), single sweeps behind a wrap each (0)
     int steps_per_launch_req = 0;  // 0 = auto, 1, 2 (2D / 3D), 4 (2D row-streaming kernel), 2 / 4 / 8 (1D)
     int steps_per_launch = 1;      // resolved
     bool generic = false;  // odd innermost extent: rows are only 8-byte aligned, the tiled kernels do not apply
@@ -126,6 +127,10 @@ enum HaloMode { HALO_COPY = 0, HALO_ZERO = 1, HALO_WRAP = 2 };
 hipError_t launch_halo(const Plan &p, void *dst, const void *src, int mode, hipStream_t s);
 // rows x cols doubles between two strided arrays (pack / unpack of a block decomposition's column ghost zones)
 hipError_t launch_copy_block(double *dst, long dst_ld, const double *src, long src_ld, long rows, long cols, hipStream_t s);
+// the torus by ghost zones (capi.cpp: run_torus): wrap of a ring of any width, interior-to-interior copies
+hipError_t launch_ring_wrap(int dtype, int nd, const int *dims, const int *ring, void *ptr, hipStream_t s);
+hipError_t launch_copy_interior(int dtype, int nd, const int *dims, void *dst, const int *pad_dst, const void *src, const int *pad_src,
+                                hipStream_t s);
 const char *kernel_name_2d_fused2(const Plan &p);
 // the same two applications per launch, row-streaming form (wave-autonomous column strips)
 // (K = 2 or 4 applications per launch)
@@ -192,4 +197,13 @@ struct lora_plan {
     void *scratch = nullptr;
     size_t scratch_bytes = 0;
     int scratch_device = -1;
+    // the periodic option's fused runs (run_torus): a plan of the grid extended by a ghost zone on every side, its two
+    // buffers, the ghost widths; rebuilt when the plan's taps / options change
+    lora_plan *torus = nullptr;
+    void *torus_buf[2] = {nullptr, nullptr};
+    size_t torus_bytes = 0;
+    int torus_device = -1;
+    int torus_ghost[3] = {0, 0, 0};
+    unsigned torus_epoch = 0;
+    bool torus_tried = false;  // at torus_epoch: the answer was already "no" (grid too small, no fused kernel, no memory)
 };

@@ -153,4 +153,70 @@ hipError_t launch_copy_block(double *dst, long dst_ld, const double *src, long s
     return hipGetLastError();
 }
 
+// ---- the torus by ghost zones (capi.cpp: run_torus) -----------------------------------------------------------------
+// Every cell of a padded array outside its interior becomes the periodic image of an interior cell: launch_halo's WRAP
+// with any ring width (the pad plus the ghost zone of an extended grid), the interior given by its extents.
+hipError_t launch_ring_wrap(int dtype, int nd, const int *dims, const int *ring, void *ptr, hipStream_t s) {
+    HaloArgs a;
+    a.nd = nd;
+    for (int d = 0; d < 3; ++d) {
+        const int sd = d - (3 - nd);
+        a.ext[d] = sd >= 0 ? dims[sd] : 1;
+        a.halo[d] = sd >= 0 ? ring[sd] : 0;
+        if (a.halo[d] > a.ext[d]) return hipErrorInvalidValue;  // the wrap source would be a ring cell itself
+    }
+    const long P1 = a.ext[1] + 2 * a.halo[1], P2 = a.ext[2] + 2 * a.halo[2];
+    const long total = 2 * a.halo[0] * P1 * P2 + a.ext[0] * 2 * a.halo[1] * P2 + a.ext[0] * a.ext[1] * 2 * a.halo[2];
+    if (total <= 0) return hipSuccess;
+    const long want = (total + 255) / 256;
+    const int blocks = (int) (want > 8192 ? 8192 : want);
+    if (dtype == LORA_BF16)
+        hipLaunchKernelGGL(halo_kernel<unsigned short>, dim3(blocks), dim3(256), 0, s, static_cast<unsigned short *>(ptr),
+                           static_cast<const unsigned short *>(nullptr), a, (int) HALO_WRAP, total);
+    else
+        hipLaunchKernelGGL(halo_kernel<double>, dim3(blocks), dim3(256), 0, s, static_cast<double *>(ptr),
+                           static_cast<const double *>(nullptr), a, (int) HALO_WRAP, total);
+    return hipGetLastError();
+}
+
+namespace {
+// an e0 x e1 x e2 box of 8-byte units between two arrays with their own row and plane strides (in units)
+__global__ void copy_box_kernel(double *__restrict__ dst, long dst_row, long dst_plane, const double *__restrict__ src, long src_row,
+                                long src_plane, long e0, long e1, long e2) {
+    const long total = e0 * e1 * e2;
+    for (long k = (long) blockIdx.x * blockDim.x + threadIdx.x; k < total; k += (long) gridDim.x * blockDim.x) {
+        const long i = k / (e1 * e2), rem = k - i * (e1 * e2), j = rem / e2, c = rem - j * e2;
+        dst[i * dst_plane + j * dst_row + c] = src[i * src_plane + j * src_row + c];
+    }
+}
+}  // namespace
+
+// The interiors of two padded arrays of one shape and dtype, `dims` cells each, the arrays padded by `pad_dst` / `pad_src`
+// per side (their halo, or halo + ghost zone): dst interior <- src interior.  Rows move as 8-byte units (bf16 rows are a
+// multiple of 8 cells behind a pad that is a multiple of 4: whole units).
+hipError_t launch_copy_interior(int dtype, int nd, const int *dims, void *dst, const int *pad_dst, const void *src, const int *pad_src,
+                                hipStream_t s) {
+    long e[3] = {1, 1, 1}, pd[3] = {0, 0, 0}, ps[3] = {0, 0, 0};
+    for (int d = 0; d < 3; ++d) {
+        const int sd = d - (3 - nd);
+        if (sd >= 0) {
+            e[d] = dims[sd];
+            pd[d] = pad_dst[sd];
+            ps[d] = pad_src[sd];
+        }
+    }
+    const long per = dtype == LORA_BF16 ? 4 : 1;  // cells per 8-byte unit
+    if (e[2] % per || pd[2] % per || ps[2] % per) return hipErrorInvalidValue;
+    const long drow = (e[2] + 2 * pd[2]) / per, srow = (e[2] + 2 * ps[2]) / per;
+    const long dplane = drow * (e[1] + 2 * pd[1]), splane = srow * (e[1] + 2 * ps[1]);
+    double *d0 = static_cast<double *>(dst) + pd[0] * dplane + pd[1] * drow + pd[2] / per;
+    const double *s0 = static_cast<const double *>(src) + ps[0] * splane + ps[1] * srow + ps[2] / per;
+    const long total = e[0] * e[1] * (e[2] / per);
+    if (total <= 0) return hipSuccess;
+    const long want = (total + 255) / 256;
+    const int blocks = (int) (want > 16384 ? 16384 : want);
+    hipLaunchKernelGGL(copy_box_kernel, dim3(blocks), dim3(256), 0, s, d0, drow, dplane, s0, srow, splane, e[0], e[1], e[2] / per);
+    return hipGetLastError();
+}
+
 }  // namespace lora

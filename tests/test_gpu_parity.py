@@ -1170,6 +1170,62 @@ def test_boundary_condition_options(L, O, shape, dims, bc):
             assert rel_err(got, exp) < 1e-13
 
 
+@pytest.mark.parametrize("shape,dims,dtype", [("star2d1r", (64, 128), "f64"), ("star2d1r", (53, 247), "f64"), ("box2d3r", (40, 130), "f64"),
+                                              ("star2d3r", (200, 380), "f64"), ("star3d1r", (9, 20, 136), "f64"),
+                                              ("box3d1r", (33, 35, 130), "f64"), ("star3d1r", (40, 70, 200), "f64"),
+                                              ("1d1r", (4096,), "f64"), ("box3d1r", (21, 37, 136), "bf16"),
+                                              ("star2d1r", (300, 1000), "f64")])
+def test_periodic_runs_in_fused_launches_on_a_ghost_extended_grid(L, O, shape, dims, dtype):
+    """The torus by ghost zones (capi.cpp: run_torus): a periodic run goes through the ordinary fused kernels on a grid
+    extended by radius x applications cells of periodic images on every side, re-wrapped after every launch.  Equal to the
+    oracle's wrap-then-sweep restatement and to the single-sweep path (option torus = 0: to rounding in fp64, bit for bit
+    in bf16; test_boundary_condition_options holds the exact-integer runs); the launches are fused ones; the result's halo
+    is the periodic image of its interior."""
+    import torch
+
+    rng = np.random.default_rng(len(dims) * 100 + dims[0])
+    ps = O.padded_shape(shape, dims)
+    w = O.effective_weights(shape)
+    w = w / w.sum()
+    if dtype == "bf16":
+        a = O.from_bf16(O.to_bf16(rng.standard_normal(ps)))
+        tdt = torch.bfloat16
+    else:
+        a = rng.standard_normal(ps)
+        tdt = torch.float64
+
+    def run(t, torus):
+        plan = L.Plan(shape, dims, dtype=dtype).set_weights(w).set_boundary("periodic").set_option("torus", torus)
+        b0 = torch.from_numpy(a).to(tdt).cuda()
+        b1 = torch.zeros_like(b0)
+        prof = plan.run_profiled(b0, b1, t)
+        torch.cuda.synchronize()
+        return (b0, b1)[t % 2].double().cpu().numpy(), prof
+
+    for t in (2, 6, 7, 13, 20):
+        got, prof = run(t, 1)
+        single, prof1 = run(t, 0)
+        assert prof1.fused_launches == 0 and prof1.single_launches == t
+        assert prof.fused_launches + prof.two_launches > 0, (shape, dims, t)  # (t = 2: one two-application launch)
+        assert prof.fused_launches * prof.apps_per_fused_launch <= t
+        if dtype == "f64":
+            # (real data: the fused 2D kernels and the separable 3D box sum in another order than the single sweep's tap loop)
+            assert rel_err(got, single) < 1e-12, (shape, dims, t)
+        else:
+            assert np.array_equal(got, single), (shape, dims, t)  # bf16: every level rounded as a single sweep stores it
+        if dtype == "f64":
+            assert rel_err(got, O.run_bc(shape, a, t, "periodic", weights=w)) < 1e-12, (shape, dims, t)
+        h = L.ops.halo(shape)
+        inner = got[tuple(slice(k, -k) for k in h)]
+        assert np.array_equal(got, np.pad(inner, [(k, k) for k in h], mode="wrap"))
+    # grids smaller than a ghost zone keep the single sweeps
+    small = {1: (64,), 2: (20, 64), 3: (4, 8, 16)}[len(dims)]
+    plan = L.Plan(shape, small, dtype=dtype).set_boundary("periodic")
+    b0 = torch.zeros(L.padded_shape(shape, small), dtype=tdt, device="cuda")
+    prof = plan.run_profiled(b0, torch.zeros_like(b0), 8)
+    assert prof.fused_launches == 0 and prof.single_launches == 8
+
+
 def test_plan_halo_modes(L, O):
     """lora_plan_halo: copy / zero / wrap of every cell outside the interior, any shape, fp64 and bf16."""
     import torch
