@@ -257,9 +257,10 @@ def test_kernel_signature_names_every_selecting_option(L):
     s6 = p.kernel_signature
     p.set_option("wg_edge_pct", 20)
     assert p.kernel_signature != s6
-    # plain 49-tap tables (no low-rank form) keep four applications per launch; the Dirichlet option runs four too
+    # plain 49-tap tables (no low-rank form) run six applications per launch too (eval = 2: the taps one by one); the
+    # Dirichlet option runs four
     q = L.Plan("star2d1r", (256, 512)).set_weights(np.random.default_rng(3).random(49))
-    assert q.get_option("steps_per_launch") == 4 and q.kernel_name == "stencil2d_stream_kernel"
+    assert q.get_option("steps_per_launch") == 6 and q.kernel_name == "stencil2d_wg_kernel" and "eval=2" in q.kernel_signature
     assert L.Plan("star2d1r", (256, 512)).set_boundary("dirichlet").get_option("steps_per_launch") == 4
     p = L.Plan("star2d1r", (16384, 16384)).set_option("steps_per_launch", 4)
     assert p.kernel_name == "stencil2d_stream_kernel"  # row-streaming, four applications
