@@ -428,7 +428,7 @@ hipError_t launch_lanes_t(const Plan &p, const double *in, double *out, int begi
         a.zc = std::min(p.fused_z_chunk, end - begin);
     } else {
         const int zc_model = chunk_model(tiles, depth, S, slots, 8 * K, nullptr);
-        const bool spans = p.spans3 == 1 || (p.spans3 < 0 && spans_pay(tiles, depth, S, slots, zc_model, 8.0 * (double) a.plane * (double) depth, (TAPSET == TAPS3D_SEP ? 0.0 : 300.0e6)));
+        const bool spans = p.spans3 == 1 || (p.spans3 < 0 && spans_pay(tiles, depth, S, slots, zc_model, 8.0 * (double) a.plane * (double) depth, 300.0e6));
         if (spans) nblocks = spans_setup(a.sp, a.tiles_x, a.tiles_y, depth, S, slots, 10, 9);
         if (nblocks == 0) a.zc = zc_model;  // (or a line that does not fit 31 bits of cost units)
     }

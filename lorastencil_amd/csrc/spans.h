@@ -70,15 +70,17 @@ inline int chunk_model(long tiles, long depth, int S, long slots, long min_chunk
     return (int) ((depth + best_c - 1) / best_c);
 }
 
-// Do spans pay?  By measurement (tools/spans_sweep.py, profiles/r04_spans_sweep_*.jsonl), not by the step counts alone:
-// spans always take fewer CYCLES (768^3 bf16: 14.2 M against 15.8 M per launch), but neighbouring tiles are no longer at the
-// same depth at the same time, so the rows they share and the 128-byte lines their misaligned row pieces straddle come
-// from HBM twice (768^3 bf16: 1.82 GB fetched against 1.19 GB) -- and with that traffic the clock sinks (1.77 GHz from the
-// third launch on against 2.0 GHz: 1000 us against 867 us).  So: spans where their busiest workgroup runs at least 3 %
-// fewer steps than the chunked launch's (whole rounds of workgroups), and either the kernel has the memory system to
-// spare at any size (`bytes_cap` = 0: the fp64 separable-box kernel, +5 - 18 % at 768^3 / 512^3) or the region's input fits
-// the 256 MB Infinity Cache (the bf16 kernel: +5 - 12 % on 64 - 192 x 768^2, -2.5 % at 384, -20 % at 768; the fp64 star
-// kernel: +27 % on 32 x 512^2, +6 % on 128 x 512^2, -6 - 10 % at 512^3 and 768^3).
+// Do spans pay?  By measurement (tools/spans_sweep.py, profiles/r04_spans_sweep_*.jsonl, r04_spans_vs_chunks_pmc.txt), not
+// by the step counts alone: spans always take fewer CYCLES (768^3 bf16: 14.2 M against 15.8 M per launch), but neighbouring
+// tiles are no longer at the same depth at the same time, so the rows they share and the 128-byte lines their misaligned
+// row pieces straddle come from HBM twice (768^3 bf16: 1.82 GB fetched against 1.19 GB) -- and with that traffic the clock
+// sinks (1.77 GHz from the third launch on against 2.0 GHz: 1000 us against 867 us).  In short bursts the fp64 separable
+// box gained 5 - 18 % at 768^3 / 512^3; over the 50 sweeps of a bench.py run it did not (790 - 900 against a steady
+// 851 - 865 GStencils/s at 768^3, tools/spans_bench_ab.sh) -- the same clock effect on a slower fuse.  So: spans where their
+// busiest workgroup runs at least 3 % fewer steps than the chunked launch's (whole rounds of workgroups) AND the region's
+// input is small enough for the 256 MB Infinity Cache to serve the second fetches (`bytes_cap`; bf16: + 5 - 12 % on
+// 64 - 192 x 768^2, - 2.5 % at 384, - 20 % at 768; fp64 star: + 27 % on 32 x 512^2, + 6 % on 128 x 512^2, - 6 - 10 % at 512^3 and
+// 768^3) -- the z-slabs and end regions of the multi-GPU drivers, mostly.
 inline bool spans_pay(long tiles, long depth, int S, long slots, int zc_model, double bytes, double bytes_cap) {
     const long wgs = tiles * ((depth + zc_model - 1) / zc_model), rounds = (wgs + slots - 1) / slots;
     const double chunk_steps = (double) rounds * (double) (zc_model + S);
