@@ -175,7 +175,7 @@ int lora_set_default_normalize(int on);
  *   steps_per_launch  0 auto / 1 / 2 (2D also 4 with the row-streaming kernel and 6 with the workgroup-row kernel, 3D fp64
  *                     also 3 with the plane-streaming kernel, 1D also 4, 8, 16, 32) : applications per launch in
  *                     lora_plan_run (temporal fusion).  2D auto: 6 (reference boundary; what six leave of a run is covered by
- *                     one launch of four and / or two); 4 for plain 49-tap tables and under the Dirichlet option.  1D auto:
+ *                     one launch of four and / or two), plain 49-tap tables included; 4 under the Dirichlet option.  1D auto:
  *                     the plan's own depth is 8 (lora_plan_stepk, slabs); lora_plan_run uses 16 from 32 sweeps on and
  *                     32 from 64 on
  *   rows_per_thread, panel_width, nt_store, fused_rows, persistent      2D tile shape / block->tile map / stores
@@ -207,6 +207,13 @@ int lora_set_default_normalize(int on);
  *                     wg_edge_pct (how much shorter the chunks of the first / last column strip are, per cent; -1 = 60),
  *                     wg_prio (log2 of the time slice, in 10 ns ticks, of the alternating wave priorities that share a
  *                     CU evenly between its two workgroups; 0 = off)
+ *   spans3            3D register-resident kernels (fp64 and bf16, four applications per launch): how a launch is cut along
+ *                     z.  0 = equal chunks per tile, 1 = spans (the line of all (tile, plane) pairs in equal pieces, one per
+ *                     resident workgroup; csrc/spans.h), -1 (default) = spans where they were measured to pay: regions
+ *                     that fit the Infinity Cache.  Same bits either way
+ *   torus             periodic boundary: 1 (default) = lora_plan_run goes through fused launches on a grid extended by a
+ *                     ghost zone of periodic images on every side (two more buffers); 0 = single sweeps behind a halo wrap
+ *                     each.  Grids smaller than a ghost zone and plans with steps_per_launch = 1 use the latter anyway
  * ("ablate", the load/store-removing timing experiment of round 1, exists only in -DLORA_DIAGNOSTICS builds of the
  * library; the shipped one answers LORA_EINVAL.)
  * lora_plan_get_option also reads the resolved "tapset", "variant", "fused_eval", "boundary". */
