@@ -254,6 +254,11 @@ int lora_plan_stepk_region(lora_plan *plan, const void *d_in, void *d_out, int b
  * (2D workgroup-row kernel: 4 and 2 under a six-application plan; 1D: powers of two below the plan's depth; else 2).
  * LORA_EUNSUPPORTED for a depth the plan's kernels do not have. */
 int lora_plan_stepn_region(lora_plan *plan, int napps, const void *d_in, void *d_out, int begin, int end, void *stream);
+/* The same over TWO disjoint ranges [begin0, end0) and [begin1, end1): what a slab or block driver sweeps behind its
+ * deferred wait (the two ends of its share).  One launch where the kernel family takes two ranges (the register-resident 3D
+ * kernels), two launches otherwise; an empty range is skipped. */
+int lora_plan_stepn_region2(lora_plan *plan, int napps, const void *d_in, void *d_out, int begin0, int end0, int begin1, int end1,
+                            void *stream);
 /* Halo cells of a padded device array (every cell outside the interior, any shape / dtype of the plan): copied from
  * d_src (LORA_HALO_COPY), zeroed (LORA_HALO_ZERO) or wrapped from d_dst's own opposite interior edges
  * (LORA_HALO_WRAP, periodic; LORA_EUNSUPPORTED if an extent is smaller than its halo).  What lora_plan_run uses for

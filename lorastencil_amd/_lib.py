@@ -185,6 +185,7 @@ SIGNATURES = {
     "lora_plan_step2_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lora_plan_stepk_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lora_plan_stepn_region": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "lora_plan_stepn_region2": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "lora_plan_run": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),
     "lora_plan_destroy": (None, [_vp]),
     "lora_default_params": (ctypes.c_int, [ctypes.c_int, _dp]),

@@ -95,6 +95,10 @@ int sweep(lora_block *s, int napps, const void *src, void *dst, int b, int e) {
     if (e <= b) return LORA_OK;
     return lora_plan_stepn_region(s->plan, napps, src, dst, b, e, s->cs);
 }
+// two ranges in one call (one launch where the kernel family takes two: lora_plan_stepn_region2)
+int sweep2(lora_block *s, int napps, const void *src, void *dst, int b0, int e0, int b1, int e1) {
+    return lora_plan_stepn_region2(s->plan, napps, src, dst, b0, e0, b1, e1, s->cs);
+}
 
 int wait_b(lora_block *s) {
     if (s->pending_b) {
@@ -253,8 +257,7 @@ int launch_all(lora_block **ss, int n, int napps) {
             if (int rc = wait_b(s)) return rc;
             if (int rc = sweep(s, napps, src, dst, a, b)) return rc;
             if (int rc = flush(s)) return rc;
-            if (int rc = sweep(s, napps, src, dst, lo / s->gran * s->gran, a)) return rc;
-            if (int rc = sweep(s, napps, src, dst, b, hi)) return rc;
+            if (int rc = sweep2(s, napps, src, dst, lo / s->gran * s->gran, a, b, hi)) return rc;
         } else {
             if (int rc = flush(s)) return rc;
             if (int rc = sweep(s, napps, src, dst, lo / s->gran * s->gran, hi)) return rc;

@@ -1213,6 +1213,35 @@ struct RunMarks {  // lora_plan_run_profiled: events around the fused and the si
     int fused_launches = 0, two_launches = 0, single_launches = 0;
 };
 
+// Two ranges of planes / rows in one call: the two end regions a slab or block driver sweeps behind its deferred wait.
+// The register-resident 3D kernels take both in ONE launch (an end region of 4 planes is 13 steps of pipeline whatever it
+// computes: 32 us each at 64 x 512^2, tools/region_split_time.py); every other kernel family gets two launches.
+int lora_plan_stepn_region2(lora_plan *plan, int napps, const void *d_in, void *d_out, int begin0, int end0, int begin1, int end1,
+                            void *stream) {
+    if (!plan || napps < 1) return LORA_EINVAL;
+    Plan &p = plan->p;
+    if (end0 <= begin0) return end1 <= begin1 ? LORA_OK : lora_plan_stepn_region(plan, napps, d_in, d_out, begin1, end1, stream);
+    if (end1 <= begin1) return lora_plan_stepn_region(plan, napps, d_in, d_out, begin0, end0, stream);
+    const bool lanes = p.ndim == 3 && p.lanes3_active && (napps == 4 || napps == 2) && napps <= p.steps_per_launch;
+    const bool apart = end0 <= begin1 || end1 <= begin0;
+    if (lanes && apart) {
+        if (int rc = lora::check_buffers(d_in, d_out)) return rc;
+        if (d_in == d_out || begin0 < 0 || end0 > p.dims[0] || begin1 < 0 || end1 > p.dims[0]) return LORA_EINVAL;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        const hipError_t e = p.dtype == LORA_BF16
+                                 ? lora::launch_3d_bf16_lanes(p, napps, d_in, d_out, begin0, end0, s, begin1, end1)
+                                 : lora::launch_3d_lanes(p, napps, static_cast<const double *>(d_in), static_cast<double *>(d_out), begin0,
+                                                         end0, s, begin1, end1);
+        if (e != hipSuccess) {
+            lora::set_last_error("fused register-resident 3D kernel launch (two ranges)", e);
+            return LORA_EHIP;
+        }
+        return LORA_OK;
+    }
+    if (int rc = lora_plan_stepn_region(plan, napps, d_in, d_out, begin0, end0, stream)) return rc;
+    return lora_plan_stepn_region(plan, napps, d_in, d_out, begin1, end1, stream);
+}
+
 // ---- the periodic option in fused launches: the torus by ghost zones ---------------------------------------------
 // A fused launch cannot wrap the halo of its intermediate levels, so rounds 1 - 3 ran periodic grids one sweep at a time
 // behind a halo wrap each.  What the slab drivers do for a cut serves for the torus too: extend the grid by a ghost zone

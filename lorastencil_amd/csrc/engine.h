@@ -151,7 +151,7 @@ hipError_t launch_3d_stream(const Plan &p, int K, const double *in, double *out,
                             int begin, int end, hipStream_t s);
 const char *kernel_name_3d_stream(const Plan &p);
 // K = 4 (or 2) applications per launch with the levels in registers (star / exactly separable box taps, fp64, any extents)
-hipError_t launch_3d_lanes(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s);
+hipError_t launch_3d_lanes(const Plan &p, int K, const double *in, double *out, int begin, int end, hipStream_t s, int begin2 = 0, int end2 = 0);
 const char *kernel_name_3d_lanes(const Plan &p);
 bool prepare_3d_lanes(const Plan &p);
 int stream3_slots(int K, int waves, int pipe, int requested);
@@ -165,7 +165,7 @@ const char *kernel_name_3d_bf16(const Plan &p);
 hipError_t launch_3d_bf16_fused2(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s);
 const char *kernel_name_3d_bf16_fused2(const Plan &p);
 // bf16, exactly separable box taps: K = 4 (or 2) applications per launch with the levels in registers (kernels_3d_bf16_lanes.hip)
-hipError_t launch_3d_bf16_lanes(const Plan &p, int K, const void *in, void *out, int begin, int end, hipStream_t s);
+hipError_t launch_3d_bf16_lanes(const Plan &p, int K, const void *in, void *out, int begin, int end, hipStream_t s, int begin2 = 0, int end2 = 0);
 const char *kernel_name_3d_bf16_lanes(const Plan &p);
 bool prepare_3d_bf16_lanes(const Plan &p);  // false: no workgroup of it fits a CU of the current device
 // bf16 box, two applications per launch, in-plane passes on v_mfma_f32_16x16x32_bf16 (LORA_VARIANT_MFMA)

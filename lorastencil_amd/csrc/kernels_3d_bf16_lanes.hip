@@ -93,6 +93,7 @@ struct ArgsBL {
     int ld;
     long plane;
     int z_begin, z_end;
+    int z_begin2, z_end2;  // a second range of planes in the same launch (chunks only): the two end regions of a slab
     int zc;
     int tiles_x, tiles_y;
     Spans sp;  // zc == 0: spans (spans.h)
@@ -307,9 +308,11 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
         k0 = a.z_begin + z0;
     } else {
         int chunk;
-        chunk_of(lin, (a.z_end - a.z_begin + a.zc - 1) / a.zc, TX, TY, chunk, tx, ty);
-        k0 = a.z_begin + chunk * a.zc;
-        zc = min(a.zc, a.z_end - k0);
+        const int c0 = (a.z_end - a.z_begin + a.zc - 1) / a.zc, c1 = (a.z_end2 - a.z_begin2 + a.zc - 1) / a.zc;
+        chunk_of(lin, c0 + c1, TX, TY, chunk, tx, ty);
+        const int zb = chunk < c0 ? a.z_begin : a.z_begin2, ze = chunk < c0 ? a.z_end : a.z_end2;
+        k0 = zb + (chunk < c0 ? chunk : chunk - c0) * a.zc;
+        zc = min(a.zc, ze - k0);
         more = false;
     }
     // (the segment before is done with the rows in LDS when its slowest wave is)
@@ -672,7 +675,7 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
 #undef LORA_BL_T1
 
 template <int K, int NW>
-hipError_t launch_t(const Plan &p, const void *in, void *out, int begin, int end, hipStream_t s) {
+hipError_t launch_t(const Plan &p, const void *in, void *out, int begin, int end, int begin2, int end2, hipStream_t s) {
     constexpr int OH = 4 * NW - 2 * K;
     auto kernel = stencil3d_bf16_lanes_kernel<K, NW>;
     static int per_cu[64] = {0};  // resolved once per device (and with it the kernel itself: lora_plan_create's share)
@@ -691,7 +694,7 @@ hipError_t launch_t(const Plan &p, const void *in, void *out, int begin, int end
         per_cu[dev] = nb;
     }
     if (per_cu[dev] < 0) return hipErrorLaunchOutOfResources;
-    if (end <= begin) return hipSuccess;  // prepare_3d_bf16_lanes()
+    if (end <= begin && end2 <= begin2) return hipSuccess;  // prepare_3d_bf16_lanes()
     ArgsBL a{};
     a.in = static_cast<const u16 *>(in);
     a.out = static_cast<u16 *>(out);
@@ -708,19 +711,23 @@ hipError_t launch_t(const Plan &p, const void *in, void *out, int begin, int end
     const long tiles = (long) a.tiles_x * a.tiles_y;
     // How the launch is cut along z (spans.h): chunks of option fused_z_chunk; else spans (option spans3 = 1, or by itself
     // where they pay: spans_pay); else equal chunks by the model of rounds of workgroups.
-    const long slots = (long) std::max(per_cu[dev], 1) * cus, depth = end - begin;
+    const long slots = (long) std::max(per_cu[dev], 1) * cus, depth = end - begin, depth2 = std::max(end2 - begin2, 0);
     constexpr int S = 3 * K - 1;
     long nblocks = 0;
     a.zc = 0;
+    a.z_begin2 = begin2;
+    a.z_end2 = begin2 + (int) depth2;
     if (p.fused_z_chunk > 0) {
-        a.zc = std::min(p.fused_z_chunk, end - begin);
+        a.zc = std::min((long) p.fused_z_chunk, std::max(depth, depth2));
+    } else if (depth2 > 0) {  // two ranges (a slab's end regions): chunks, as many workgroups as two ranges of the longer depth
+        a.zc = chunk_model(2 * tiles, std::max(depth, depth2), S, slots, 4 * K, nullptr);
     } else {
         const int zc_model = chunk_model(tiles, depth, S, slots, 4 * K, nullptr);
         const bool spans = p.spans3 == 1 || (p.spans3 < 0 && spans_pay(tiles, depth, S, slots, zc_model, 2.0 * (double) a.plane * (double) depth, 256.0e6));
         if (spans) nblocks = spans_setup(a.sp, a.tiles_x, a.tiles_y, depth, S, slots, 10, 9);
         if (nblocks == 0) a.zc = zc_model;  // (or a line that does not fit 31 bits of cost units)
     }
-    if (a.zc > 0) nblocks = tiles * ((depth + a.zc - 1) / a.zc);
+    if (a.zc > 0) nblocks = tiles * ((depth + a.zc - 1) / a.zc + (depth2 + a.zc - 1) / a.zc);
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
     TapsSep w;
     for (int k = 0; k < 3; ++k) {
@@ -741,14 +748,15 @@ hipError_t launch_t(const Plan &p, const void *in, void *out, int begin, int end
 }  // namespace
 
 // K = 4 (or 2) applications in one launch over interior planes [begin, end); exactly separable box taps, reference boundary
-hipError_t launch_3d_bf16_lanes(const Plan &p, int K, const void *in, void *out, int begin, int end, hipStream_t s) {
+// (and planes [begin2, end2) in the same launch: kernels_3d_lanes.hip)
+hipError_t launch_3d_bf16_lanes(const Plan &p, int K, const void *in, void *out, int begin, int end, hipStream_t s, int begin2, int end2) {
     if (p.boundary != LORA_BC_REFERENCE || p.dtype != LORA_BF16 || p.tapset != TAPS3D_SEP) return hipErrorNotSupported;
 #ifdef LORA_BL_NW  // (tools/probes/bf16_lanes_ablate.hip: another workgroup size)
-    if (K == 4) return launch_t<4, LORA_BL_NW>(p, in, out, begin, end, s);
-    if (K == 2) return launch_t<2, LORA_BL_NW>(p, in, out, begin, end, s);
+    if (K == 4) return launch_t<4, LORA_BL_NW>(p, in, out, begin, end, begin2, end2, s);
+    if (K == 2) return launch_t<2, LORA_BL_NW>(p, in, out, begin, end, begin2, end2, s);
 #else
-    if (K == 4) return launch_t<4, 16>(p, in, out, begin, end, s);
-    if (K == 2) return launch_t<2, 16>(p, in, out, begin, end, s);
+    if (K == 4) return launch_t<4, 16>(p, in, out, begin, end, begin2, end2, s);
+    if (K == 2) return launch_t<2, 16>(p, in, out, begin, end, begin2, end2, s);
 #endif
     return hipErrorInvalidValue;
 }

@@ -94,6 +94,10 @@ int sweep(lora_slab *s, int napps, const void *src, void *dst, int b, int e) {
     if (e <= b) return LORA_OK;
     return lora_plan_stepn_region(s->plan, napps, src, dst, b, e, s->cs);
 }
+// two ranges in one call (one launch where the kernel family takes two: lora_plan_stepn_region2)
+int sweep2(lora_slab *s, int napps, const void *src, void *dst, int b0, int e0, int b1, int e1) {
+    return lora_plan_stepn_region2(s->plan, napps, src, dst, b0, e0, b1, e1, s->cs);
+}
 
 int flush(lora_slab *s) {
     if (s->pending) {
@@ -208,10 +212,9 @@ int launch_all(lora_slab **ss, int n, int napps) {
                 const int st = s->strip;
                 if (s->overlap && s->own > 2 * st) {
                     overlapped = true;
-                    if (s->up >= 0)
-                        if (int rc = sweep(s, napps, src, dst, s->gt, s->gt + st)) return rc;
-                    if (s->down >= 0)
-                        if (int rc = sweep(s, napps, src, dst, s->gt + s->own - st, s->gt + s->own)) return rc;
+                    if (int rc = sweep2(s, napps, src, dst, s->gt, s->gt + (s->up >= 0 ? st : 0), s->gt + s->own - (s->down >= 0 ? st : 0),
+                                        s->gt + s->own))
+                        return rc;
                 } else {
                     if (int rc = sweep(s, napps, src, dst, s->gt, s->gt + s->own)) return rc;
                 }
@@ -250,8 +253,7 @@ int launch_all(lora_slab **ss, int n, int napps) {
                 if (s->pending && b - a >= 2 * need) {
                     if (int rc = sweep(s, napps, src, dst, a, b)) return rc;
                     if (int rc = flush(s)) return rc;
-                    if (int rc = sweep(s, napps, src, dst, lo, a)) return rc;
-                    if (int rc = sweep(s, napps, src, dst, b, hi)) return rc;
+                    if (int rc = sweep2(s, napps, src, dst, lo, a, b, hi)) return rc;
                 } else {
                     if (int rc = flush(s)) return rc;
                     if (int rc = sweep(s, napps, src, dst, lo, hi)) return rc;

@@ -388,6 +388,11 @@ class Plan:
         check(_lib.lib().lora_plan_stepn_region(self._h, int(napps), _ptr(d_in), _ptr(d_out), int(begin), int(end),
                                                 _stream(stream)), "lora_plan_stepn_region")
 
+    def stepn_region2(self, napps: int, d_in, d_out, begin0: int, end0: int, begin1: int, end1: int, stream=None):
+        """``napps`` applications over two disjoint ranges: one launch where the kernel family takes two (3D register-resident)."""
+        check(_lib.lib().lora_plan_stepn_region2(self._h, int(napps), _ptr(d_in), _ptr(d_out), int(begin0), int(end0), int(begin1),
+                                                 int(end1), _stream(stream)), "lora_plan_stepn_region2")
+
     def run_profiled(self, d_buf0, d_buf1, times: int, stream=None):
         """run() with HIP events around the fused and the single-sweep launches; blocks until the run is done.
         Returns a ``_lib.RunProfile``."""

@@ -276,6 +276,10 @@ class HipStepper:
     def step2_region(self, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
         self.plan.step2_region(src.data_ptr(), dst.data_ptr(), begin, end, stream=self.stream)
 
+    def stepn_region2(self, napps: int, src: torch.Tensor, dst: torch.Tensor, b0: int, e0: int, b1: int, e1: int) -> None:
+        """Two disjoint ranges in one call (lora_plan_stepn_region2): the two ends behind a deferred wait."""
+        self.plan.stepn_region2(napps, src.data_ptr(), dst.data_ptr(), b0, e0, b1, e1, stream=self.stream)
+
     def stepn_region(self, napps: int, src: torch.Tensor, dst: torch.Tensor, begin: int, end: int) -> None:
         """A tail launch of `napps` applications under a deeper plan (lora_plan_stepn_region)."""
         self.plan.stepn_region(napps, src.data_ptr(), dst.data_ptr(), begin, end, stream=self.stream)
@@ -587,8 +591,11 @@ class SlabDriver:
                 if self._pending and b - a >= 2 * need:
                     sweep(src, dst, a, b)
                     self._flush()
-                    sweep(src, dst, lo, a)
-                    sweep(src, dst, b, hi)
+                    if hasattr(self.stepper, "stepn_region2"):  # both ends in one call (one launch for the 3D lanes kernels)
+                        self.stepper.stepn_region2(napps, src, dst, lo, a, b, hi)
+                    else:
+                        sweep(src, dst, lo, a)
+                        sweep(src, dst, b, hi)
                 else:
                     self._flush()
                     sweep(src, dst, lo, hi)

@@ -576,6 +576,14 @@ def test_3d_register_resident_kernel_real_data_and_regions(L, O, shape):
         plan.stepk_region(src, dst, b, e)
     torch.cuda.synchronize()
     assert np.array_equal(dst.cpu().numpy(), got)
+    # two ranges in one launch (lora_plan_stepn_region2: the two ends a slab driver sweeps behind its deferred wait)
+    plan.set_option("spans3", -1)
+    for (b0, e0, b1, e1), rest in (((0, 7, 20, 45), (7, 20)), ((41, 45, 0, 4), (4, 41)), ((0, 0, 30, 45), (0, 30))):
+        dst[1:-1, 2:-2, 4:-4] = -3.0
+        plan.stepn_region2(4, src, dst, b0, e0, b1, e1)
+        plan.stepk_region(src, dst, *rest)
+        torch.cuda.synchronize()
+        assert np.array_equal(dst.cpu().numpy(), got), (b0, e0, b1, e1)
     for cut in (1, 0):  # the same regions cut into spans / into the model's chunks
         dst[1:-1, 2:-2, 4:-4] = -3.0
         plan.set_option("spans3", cut)
@@ -1013,6 +1021,30 @@ def test_bf16_register_resident_kernel_equals_step_by_step(L, O, dims):
     general = L.Plan(shape, dims, dtype="bf16").set_weights(wr).set_option("steps_per_launch", 4)
     assert general.kernel_name == "stencil3d_bf16_fused2_kernel" and general.get_option("steps_per_launch") == 2
     assert L.Plan("star3d1r", dims, dtype="bf16").set_option("steps_per_launch", 4).kernel_name == "stencil3d_bf16_fused2_kernel"
+
+
+def test_bf16_register_resident_kernel_two_ranges_in_one_launch(L, O):
+    """lora_plan_stepn_region2 on a bf16 grid: the two end regions in ONE launch of the register-resident kernel + the
+    interior == one launch over all planes, bit for bit; four and two applications."""
+    import torch
+
+    shape, dims = "box3d1r", (45, 70, 248)
+    rng = np.random.default_rng(77)
+    w = O.effective_weights(shape)
+    w = w / w.sum()
+    bits = O.to_bf16(rng.standard_normal(O.padded_shape(shape, dims)))
+    plan = L.Plan(shape, dims, dtype="bf16").set_weights(w).set_option("steps_per_launch", 4)
+    assert plan.kernel_name == "stencil3d_bf16_lanes_kernel"
+    src = torch.from_numpy(bits.view(np.int16).copy()).cuda().view(torch.bfloat16)
+    for napps in (4, 2):
+        whole = src.clone()
+        plan.stepn_region(napps, src, whole, 0, dims[0])
+        for (b0, e0, b1, e1), rest in (((0, 4, 41, 45), (4, 41)), ((30, 45, 0, 9), (9, 30))):
+            dst = src.clone()
+            plan.stepn_region2(napps, src, dst, b0, e0, b1, e1)
+            plan.stepn_region(napps, src, dst, *rest)
+            torch.cuda.synchronize()
+            assert torch.equal(dst.view(torch.int16), whole.view(torch.int16)), (napps, b0, e0, b1, e1)
 
 
 @pytest.mark.parametrize("dims", [(8, 28, 64), (9, 31, 248), (5, 3, 8), (37, 64, 360), (40, 61, 128)])
