@@ -209,8 +209,9 @@ int lora_set_default_normalize(int on);
  *                     CU evenly between its two workgroups; 0 = off)
  *   spans3            3D register-resident kernels (fp64 and bf16, four applications per launch): how a launch is cut along
  *                     z.  0 = equal chunks per tile, 1 = spans (the line of all (tile, plane) pairs in equal pieces, one per
- *                     resident workgroup; csrc/spans.h), -1 (default) = spans where they were measured to pay: regions
- *                     that fit the Infinity Cache.  Same bits either way
+ *                     resident workgroup; csrc/spans.h), 2 = team spans (the line over tile rows, a piece per team of a
+ *                     row's workgroups), -1 (default) = by measurement: spans on regions that fit the Infinity Cache, team
+ *                     spans on bigger bf16 grids where they save steps, chunks otherwise.  Same bits every way
  *   torus             periodic boundary: 1 (default) = lora_plan_run goes through fused launches on a grid extended by a
  *                     ghost zone of periodic images on every side (two more buffers); 0 = single sweeps behind a halo wrap
  *                     each.  Grids smaller than a ghost zone and plans with steps_per_launch = 1 use the latter anyway

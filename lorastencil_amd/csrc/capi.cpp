@@ -759,7 +759,7 @@ int lora_plan_set_option(lora_plan *plan, const char *key, int value) {
         if (value < 0 || value > 4096) return LORA_EINVAL;
         p.fused_z_chunk = value;
     } else if (!std::strcmp(key, "spans3")) {
-        if (value < -1 || value > 1) return LORA_EINVAL;
+        if (value < -1 || value > 2) return LORA_EINVAL;
         p.spans3 = value;
     } else if (!std::strcmp(key, "torus")) {
         p.torus = value ? 1 : 0;

@@ -72,6 +72,7 @@ struct ArgsL3 {
     int zc;
     int tiles_x, tiles_y;
     Spans sp;  // zc == 0: spans (spans.h)
+    int team;  // zc == 0: 0 = a span per workgroup over all tiles; TX = a span per TEAM of the TX workgroups of a tile row
 };
 
 __device__ __forceinline__ double lane_below(double v) {  // the value lane i - 1 holds (0 in lane 0)
@@ -108,12 +109,19 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
     // (they run the slower EDGE steps throughout, and with the long workgroups dispatched first the short ones even out
     // the end of the launch).
     unsigned v0 = 0, v1 = 0;
-    if (a.zc == 0) span_range(a.sp, lin, v0, v1);
+    if (a.zc == 0) span_range(a.sp, a.team ? lin / a.team : lin, v0, v1);
     for (bool more = true, first = true; more; first = false) {
     int tx, ty, k0, zc;
     if (a.zc == 0) {
         int z0;
-        const bool any = span_next(a.sp, 2 * K + 1, v0, v1, TX, TY, tx, ty, z0, zc);
+        bool any;
+        if (a.team) {  // the line runs over tile ROWS; this workgroup is column lin mod TX of its team's row
+            int t0;
+            any = span_next(a.sp, 2 * K + 1, v0, v1, 1, TY, t0, ty, z0, zc);
+            tx = lin - (lin / a.team) * a.team;
+        } else {
+            any = span_next(a.sp, 2 * K + 1, v0, v1, TX, TY, tx, ty, z0, zc);
+        }
         more = v0 < v1;
         if (!any) continue;
         k0 = a.z_begin + z0;
@@ -435,8 +443,16 @@ hipError_t launch_lanes_t(const Plan &p, const double *in, double *out, int begi
         a.zc = chunk_model(2 * tiles, std::max(depth, depth2), S, slots, 8 * K, nullptr);
     } else {
         const int zc_model = chunk_model(tiles, depth, S, slots, 8 * K, nullptr);
-        const bool spans = p.spans3 == 1 || (p.spans3 < 0 && spans_pay(tiles, depth, S, slots, zc_model, 8.0 * (double) a.plane * (double) depth, 300.0e6));
-        if (spans) nblocks = spans_setup(a.sp, a.tiles_x, a.tiles_y, depth, S, slots, 10, 9);
+        const bool spans = p.spans3 >= 1 || (p.spans3 < 0 && spans_pay(tiles, depth, S, slots, zc_model, 8.0 * (double) a.plane * (double) depth, 300.0e6));
+        if (p.spans3 == 2 && a.tiles_x <= slots) {  // (by option only: measured 4 - 9 % slower than chunks on fp64 grids, spans.h)
+            // TEAM spans: the line runs over tile rows and is cut into one piece per team of tiles_x workgroups, one per
+            // tile of the row -- x-neighbours stay at the same depth (and, dealt out contiguously, in the same XCD's L2)
+            const long nteams = spans_setup(a.sp, 1, a.tiles_y, depth, S, slots / a.tiles_x, 1, 1);
+            a.team = a.tiles_x;
+            nblocks = nteams * a.tiles_x;
+        } else if (spans) {
+            nblocks = spans_setup(a.sp, a.tiles_x, a.tiles_y, depth, S, slots, 10, 9);
+        }
         if (nblocks == 0) a.zc = zc_model;  // (or a line that does not fit 31 bits of cost units)
     }
     if (a.zc > 0) nblocks = tiles * ((depth + a.zc - 1) / a.zc + (depth2 + a.zc - 1) / a.zc);

@@ -77,7 +77,7 @@ inline int chunk_model(long tiles, long depth, int S, long slots, long min_chunk
 // sinks (1.77 GHz from the third launch on against 2.0 GHz: 1000 us against 867 us).  In short bursts the fp64 separable
 // box gained 5 - 18 % at 768^3 / 512^3; over the 50 sweeps of a bench.py run it did not (790 - 900 against a steady
 // 851 - 865 GStencils/s at 768^3, tools/spans_bench_ab.sh) -- the same clock effect on a slower fuse.  So: spans where their
-// busiest workgroup runs at least 3 % fewer steps than the chunked launch's (whole rounds of workgroups) AND the region's
+// busiest workgroup runs fewer steps than the chunked launch's (whole rounds of workgroups) AND the region's
 // input is small enough for the 256 MB Infinity Cache to serve the second fetches (`bytes_cap`; bf16: + 5 - 12 % on
 // 64 - 192 x 768^2, - 2.5 % at 384, - 20 % at 768; fp64 star: + 27 % on 32 x 512^2, + 6 % on 128 x 512^2, - 6 - 10 % at 512^3 and
 // 768^3) -- the z-slabs and end regions of the multi-GPU drivers, mostly.
@@ -85,7 +85,22 @@ inline bool spans_pay(long tiles, long depth, int S, long slots, int zc_model, d
     const long wgs = tiles * ((depth + zc_model - 1) / zc_model), rounds = (wgs + slots - 1) / slots;
     const double chunk_steps = (double) rounds * (double) (zc_model + S);
     const double span_steps = 1.5 * S + (double) (tiles * (depth + S)) / (double) slots;  // a start, the share, half a second start
-    return span_steps < 0.97 * chunk_steps && (bytes_cap <= 0.0 || bytes <= bytes_cap);
+    return span_steps < chunk_steps && (bytes_cap <= 0.0 || bytes <= bytes_cap);
+}
+
+// TEAM spans: the line runs over tile ROWS and is cut into one piece per team of tiles_x workgroups, one per tile of the
+// row.  The tiles of a row stay at the same depth -- and, dealt out contiguously, in the same XCD's L2 -- so the lines their
+// row pieces share are fetched once, as with chunks; what is given up is the rows shared with the tile rows above and
+// below, and a team runs at the pace of its rim tiles.  Measured (tools/spans_sweep.py, tools/spans_bench_ab.sh): bf16
+// 768^3 732 us per launch against 754 (chunks) and 954 (spans), 2115 - 2134 against 2055 - 2093 GStencils/s over 50 sweeps;
+// fp64 star 512^3 and box 768^3 4 - 9 % SLOWER than chunks (their rows overlap by a quarter, the bf16 tile's by an eighth).
+// So: the bf16 kernel, on regions too big for plain spans, where a team's busiest member runs at least 3 % fewer steps.
+inline bool teams_pay(int tiles_x, int tiles_y, long depth, int S, long slots, int zc_model) {
+    if (tiles_x > slots) return false;
+    const long tiles = (long) tiles_x * tiles_y, wgs = tiles * ((depth + zc_model - 1) / zc_model), rounds = (wgs + slots - 1) / slots;
+    const double chunk_steps = (double) rounds * (double) (zc_model + S);
+    const double team_steps = 1.5 * S + (double) (tiles_y * (depth + S)) / (double) (slots / tiles_x);
+    return team_steps < 0.97 * chunk_steps;
 }
 
 #ifdef __HIPCC__

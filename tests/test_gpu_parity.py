@@ -534,8 +534,9 @@ def test_3d_register_resident_kernel_equals_step_by_step(L, O, shape, dims):
     for t in (4, 5, 6, 7, 8, 9, 12, 13):  # 12, 13: three launches of four, the last two through the scratch grid
         exp = O.run(shape, a, t)
         # every way a launch is cut along z: by the plan's own rule, fixed chunks, spans (spans.h: equal pieces of the line
-        # of all (tile, plane) pairs, workgroups that cross from one tile into the next), the model's chunks
-        for cut in ({}, {"fused_z_chunk": 3}, {"fused_z_chunk": 9}, {"fused_z_chunk": 40}, {"spans3": 1}, {"spans3": 0}):
+        # of all (tile, plane) pairs, workgroups that cross from one tile into the next), the model's chunks, team spans
+        # (the line over tile rows, a piece per team of a row's workgroups)
+        for cut in ({}, {"fused_z_chunk": 3}, {"fused_z_chunk": 9}, {"fused_z_chunk": 40}, {"spans3": 1}, {"spans3": 0}, {"spans3": 2}):
             got = plan_run(L, shape, a, t, options=dict({"steps_per_launch": 4}, **cut))
             if np.abs(exp).max() < 2.0 ** 50:
                 assert np.array_equal(got, exp), f"{shape} {dims} t={t} {cut}"
@@ -584,7 +585,7 @@ def test_3d_register_resident_kernel_real_data_and_regions(L, O, shape):
         plan.stepk_region(src, dst, *rest)
         torch.cuda.synchronize()
         assert np.array_equal(dst.cpu().numpy(), got), (b0, e0, b1, e1)
-    for cut in (1, 0):  # the same regions cut into spans / into the model's chunks
+    for cut in (1, 2, 0):  # the same regions cut into spans / team spans / the model's chunks
         dst[1:-1, 2:-2, 4:-4] = -3.0
         plan.set_option("spans3", cut)
         for b, e in ((7, 20), (20, 45), (0, 7)):
@@ -1006,7 +1007,8 @@ def test_bf16_register_resident_kernel_equals_step_by_step(L, O, dims):
     for t in (4, 5, 8, 9, 13):
         exp = O.run_bf16(shape, bits, t, weights=w)
         for opts in ({"steps_per_launch": 4}, {"steps_per_launch": 4, "fused_z_chunk": 3}, {"lanes3": 1, "fused_z_chunk": 16},
-                     {"steps_per_launch": 4, "spans3": 1}, {"steps_per_launch": 4, "spans3": 0}):  # (spans.h)
+                     {"steps_per_launch": 4, "spans3": 1}, {"steps_per_launch": 4, "spans3": 0},
+                     {"steps_per_launch": 4, "spans3": 2}):  # (spans.h: spans, chunks, team spans)
             assert np.array_equal(plan_run_bf16(L, shape, bits, t, weights=w, options=opts), exp), (dims, t, opts)
     # any exactly separable taps: a (x) b (x) c of random factors
     a, b, c = (rng.standard_normal(3).astype(np.float32) for _ in range(3))

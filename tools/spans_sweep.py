@@ -41,16 +41,18 @@ def main():
         dst = src.clone()
         pts = dims[0] * dims[1] * dims[2]
         row = {"shape": args.shape, "dtype": args.dtype, "dims": dims}
-        for name, v in (("chunks", 0), ("spans", 1), ("chunks_again", 0), ("spans_again", 1)):
+        for name, v in (("warm", 0), ("chunks", 0), ("spans", 1), ("teams", 2), ("rule", -1), ("chunks_again", 0), ("spans_again", 1),
+                        ("teams_again", 2), ("rule_again", -1)):  # (the first block runs in the clock ramp: not reported)
             plan = L.Plan(args.shape, dims, dtype=args.dtype)
             plan.set_option("steps_per_launch", 4)
             plan.set_option("spans3", v)
             us = time_plan(plan, src, dst)
+            if name == "warm":
+                continue
             row[name + "_us"] = round(us, 1)
-            row[name + "_gst"] = round(pts * 4 / us / 1e3, 1)
             row["kernel"] = plan.kernel_name
         outs = []
-        for v in (0, 1):  # the two cuts of the launch give the same bits
+        for v in (0, 1, 2):  # the cuts of the launch give the same bits
             plan = L.Plan(args.shape, dims, dtype=args.dtype)
             plan.set_option("steps_per_launch", 4)
             plan.set_option("spans3", v)
@@ -58,8 +60,8 @@ def main():
             plan.stepk(src, o)
             torch.cuda.synchronize()
             outs.append(o)
-        row["same_bits"] = bool(torch.equal(outs[0].view(torch.int16 if args.dtype == "bf16" else torch.int64),
-                                            outs[1].view(torch.int16 if args.dtype == "bf16" else torch.int64)))
+        it = torch.int16 if args.dtype == "bf16" else torch.int64
+        row["same_bits"] = bool(torch.equal(outs[0].view(it), outs[1].view(it)) and torch.equal(outs[0].view(it), outs[2].view(it)))
         del outs
         print(json.dumps(row), flush=True)
         del src, dst
