@@ -1252,6 +1252,17 @@ def test_periodic_runs_in_fused_launches_on_a_ghost_extended_grid(L, O, shape, d
         h = L.ops.halo(shape)
         inner = got[tuple(slice(k, -k) for k in h)]
         assert np.array_equal(got, np.pad(inner, [(k, k) for k in h], mode="wrap"))
+    # on a real stream a long run of a small grid is captured into a hipGraph and replayed: the extended grid's buffers are
+    # there before the capture starts; twice, so that the second run replays
+    side = torch.cuda.Stream()
+    plan = L.Plan(shape, dims, dtype=dtype).set_weights(w).set_boundary("periodic").set_option("graph", 1)
+    for _ in range(2):
+        b0 = torch.from_numpy(a).to(tdt).cuda()
+        b1 = torch.zeros_like(b0)
+        torch.cuda.synchronize()
+        plan.run(b0, b1, 20, stream=side)
+        side.synchronize()
+        assert np.array_equal(b0.double().cpu().numpy(), got), "captured run"  # (got: the 20-sweep run above)
     # grids smaller than a ghost zone keep the single sweeps
     small = {1: (64,), 2: (20, 64), 3: (4, 8, 16)}[len(dims)]
     plan = L.Plan(shape, small, dtype=dtype).set_boundary("periodic")
