@@ -18,6 +18,7 @@
 #include <string>
 
 #include "engine.h"
+#include "spans.h"
 
 namespace lora {
 
@@ -1212,6 +1213,49 @@ struct RunMarks {  // lora_plan_run_profiled: events around the fused and the si
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // start | K-launches | 2-launches | singles
     int fused_launches = 0, two_launches = 0, single_launches = 0;
 };
+
+// Test support (no device): replay, on the host, the decode the register-resident 3D kernels run for a launch cut into spans
+// (team = 0) or team spans (team = 1) -- csrc/spans.h -- and count how often each (tile, plane) pair is swept.
+// cover[(ty * tiles_x + tx) * depth + z] += 1 per workgroup segment that holds the pair; *workgroups = the launch's size,
+// *max_steps = the busiest workgroup's steps (S per segment + its planes).  Every count must be 1.
+int lora_debug_span_cover(int tiles_x, int tiles_y, int depth, int S, int slots, int team, int *cover, int *workgroups, int *max_steps) {
+    if (tiles_x < 1 || tiles_y < 1 || depth < 1 || S < 1 || slots < 1 || !cover) return LORA_EINVAL;
+    lora::Spans sp{};
+    long wgs;
+    if (team) {
+        if (tiles_x > slots) return LORA_EUNSUPPORTED;
+        wgs = lora::spans_setup(sp, 1, tiles_y, depth, S, slots / tiles_x, 1, 1) * tiles_x;
+    } else {
+        wgs = lora::spans_setup(sp, tiles_x, tiles_y, depth, S, slots, 10, 9);
+    }
+    if (wgs <= 0) return LORA_EUNSUPPORTED;
+    int busiest = 0;
+    for (long lin = 0; lin < wgs; ++lin) {
+        unsigned v0, v1;
+        lora::span_range(sp, (int) (team ? lin / tiles_x : lin), v0, v1);
+        int steps = 0;
+        for (bool more = true; more;) {
+            int tx, ty, z0, zc;
+            bool any;
+            if (team) {
+                int t0;
+                any = lora::span_next(sp, S, v0, v1, 1, tiles_y, t0, ty, z0, zc);
+                tx = (int) (lin % tiles_x);
+            } else {
+                any = lora::span_next(sp, S, v0, v1, tiles_x, tiles_y, tx, ty, z0, zc);
+            }
+            more = v0 < v1;
+            if (!any) continue;
+            if (tx < 0 || tx >= tiles_x || ty < 0 || ty >= tiles_y || z0 < 0 || z0 + zc > depth) return LORA_EHIP;  // (out of range: a bug)
+            for (int z = z0; z < z0 + zc; ++z) cover[((long) ty * tiles_x + tx) * depth + z] += 1;
+            steps += S + zc;
+        }
+        busiest = std::max(busiest, steps);
+    }
+    if (workgroups) *workgroups = (int) wgs;
+    if (max_steps) *max_steps = busiest;
+    return LORA_OK;
+}
 
 // Two ranges of planes / rows in one call: the two end regions a slab or block driver sweeps behind its deferred wait.
 // The register-resident 3D kernels take both in ONE launch (an end region of 4 planes is 13 steps of pipeline whatever it

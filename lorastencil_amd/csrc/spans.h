@@ -104,9 +104,15 @@ inline bool teams_pay(int tiles_x, int tiles_y, long depth, int S, long slots, i
 }
 
 #ifdef __HIPCC__
+#define LORA_SPANS_FN __host__ __device__ __forceinline__
+#else
+#define LORA_SPANS_FN inline
+#endif
+// (the decode below is what the kernels run; it is plain integer arithmetic and also compiles for the host, where
+// lora_debug_span_cover replays it for the tests)
 // tile t of the rim-first order -> (tx, ty): the TX x TY tiles' rim (first and last row, then first and last column), then
 // the inner tiles row by row
-__device__ __forceinline__ void rim_first_tile(int t, int TX, int TY, int &tx, int &ty) {
+LORA_SPANS_FN void rim_first_tile(int t, int TX, int TY, int &tx, int &ty) {
     if (TX < 3 || TY < 3) {
         ty = t / TX;
         tx = t - ty * TX;
@@ -128,7 +134,7 @@ __device__ __forceinline__ void rim_first_tile(int t, int TX, int TY, int &tx, i
 }
 
 // workgroup `lin` of a chunked launch (`chunks` chunks per tile) -> (chunk, tile): all chunks of the rim tiles first
-__device__ __forceinline__ void chunk_of(int lin, int chunks, int TX, int TY, int &chunk, int &tx, int &ty) {
+LORA_SPANS_FN void chunk_of(int lin, int chunks, int TX, int TY, int &chunk, int &tx, int &ty) {
     if (TX < 3 || TY < 3) {
         const int per_chunk = TX * TY;
         chunk = lin / per_chunk;
@@ -147,28 +153,27 @@ __device__ __forceinline__ void chunk_of(int lin, int chunks, int TX, int TY, in
 }
 
 // this workgroup's range [v0, v1) of the line
-__device__ __forceinline__ void span_range(const Spans &sp, int lin, unsigned &v0, unsigned &v1) {
-    v0 = (unsigned) lin * (unsigned) sp.q + (unsigned) min(lin, sp.r);
+LORA_SPANS_FN void span_range(const Spans &sp, int lin, unsigned &v0, unsigned &v1) {
+    v0 = (unsigned) lin * (unsigned) sp.q + (unsigned) (lin < sp.r ? lin : sp.r);
     v1 = v0 + (unsigned) sp.q + (lin < sp.r ? 1u : 0u);
 }
 
 // The next segment of [v0, v1): its tile and planes [z0, z0 + zc) of the region; advances v0.  A tile's first S steps'
 // worth of units stand for the start every segment pays (charged once per workgroup outside the line, so a range that
 // ENTERS a tile spends them here).  false: this piece of the range holds no plane (it ends inside a tile's start).
-__device__ __forceinline__ bool span_next(const Spans &sp, int S, unsigned &v0, unsigned v1, int TX, int TY, int &tx, int &ty,
+LORA_SPANS_FN bool span_next(const Spans &sp, int S, unsigned &v0, unsigned v1, int TX, int TY, int &tx, int &ty,
                                           int &z0, int &zc) {
     const unsigned rim_units = (unsigned) sp.nrim * (unsigned) sp.vt * (unsigned) sp.wrim;
     const bool in_rim = v0 < rim_units;
     const unsigned w = in_rim ? sp.wrim : sp.win, tile_units = (unsigned) sp.vt * w;
     const unsigned base = in_rim ? 0u : rim_units, ti = (v0 - base) / tile_units;
-    const unsigned tile_v = base + ti * tile_units, e = min(v1, tile_v + tile_units);
-    z0 = max((int) ((v0 - tile_v) / w) - S, 0);
-    const int z1 = max((int) ((e - tile_v) / w) - S, 0);
+    const unsigned tile_v = base + ti * tile_units, e = v1 < tile_v + tile_units ? v1 : tile_v + tile_units;
+    const int p0 = (int) ((v0 - tile_v) / w) - S, p1 = (int) ((e - tile_v) / w) - S;
+    z0 = p0 > 0 ? p0 : 0;
+    const int z1 = p1 > 0 ? p1 : 0;
     rim_first_tile((int) ti + (in_rim ? 0 : sp.nrim), TX, TY, tx, ty);
     v0 = e;
     zc = z1 - z0;
     return zc > 0;
 }
-#endif
-
 }  // namespace lora

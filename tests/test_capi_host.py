@@ -303,3 +303,34 @@ def test_slab_schedule_is_the_same_on_every_rank(L, shape, dims, world):
         assert layout.ghost == need * every
         seen.add((apps, need, every, layout.ghost))
     assert len(seen) == 1, seen
+
+
+@pytest.mark.parametrize("team", [0, 1])
+def test_spans_cover_every_tile_plane_exactly_once(L, team):
+    """csrc/spans.h: a launch of the register-resident 3D kernels cut into spans / team spans.  The decode the kernels run
+    is replayed on the host (lora_debug_span_cover): whatever the tile grid, depth, start length and number of resident
+    workgroups, every (tile, plane) pair is swept by exactly one segment, no workgroup decodes a pair outside the region,
+    and the busiest workgroup stays within two starts of an even share."""
+    import ctypes
+
+    from lorastencil_amd import _lib
+
+    lib = _lib.lib()
+    cases = [(7, 14, 768, 11, 256), (5, 22, 512, 9, 256), (5, 22, 64, 9, 256), (1, 1, 1, 9, 256), (2, 2, 5, 5, 256), (3, 3, 7, 11, 8),
+             (9, 19, 1024, 11, 256), (7, 32, 96, 9, 256), (1, 40, 300, 11, 304), (40, 1, 33, 5, 64), (3, 5, 1000, 9, 7), (4, 4, 2, 11, 256),
+             (13, 3, 17, 9, 100)]
+    for tx, ty, depth, S, slots in cases:
+        cover = (ctypes.c_int * (tx * ty * depth))()
+        wgs, busiest = ctypes.c_int(), ctypes.c_int()
+        rc = lib.lora_debug_span_cover(tx, ty, depth, S, slots, team, cover, ctypes.byref(wgs), ctypes.byref(busiest))
+        if team and tx > slots:
+            assert rc == L.LORA_EUNSUPPORTED if hasattr(L, "LORA_EUNSUPPORTED") else rc != 0
+            continue
+        assert rc == 0, (tx, ty, depth, S, slots)
+        counts = np.frombuffer(cover, dtype=np.int32)
+        assert counts.min() == 1 and counts.max() == 1, (tx, ty, depth, S, slots, team, int(counts.min()), int(counts.max()))
+        assert 1 <= wgs.value <= slots
+        groups = wgs.value // tx if team else wgs.value  # independent pieces of the line
+        lines = ty if team else tx * ty
+        even = lines * (depth + S) / groups
+        assert busiest.value <= 1.25 * even + 2 * S + 2, (tx, ty, depth, S, slots, team, busiest.value, even)
