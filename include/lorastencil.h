@@ -207,6 +207,9 @@ int lora_set_default_normalize(int on);
  *                     wg_edge_pct (how much shorter the chunks of the first / last column strip are, per cent; -1 = 60),
  *                     wg_prio (log2 of the time slice, in 10 ns ticks, of the alternating wave priorities that share a
  *                     CU evenly between its two workgroups; 0 = off)
+ *   lanes3            3D fused launches through the register-resident kernels (kernels_3d_lanes.hip, kernels_3d_bf16_lanes.hip:
+ *                     four applications per launch with the time levels in registers): -1 (default) by grid size (fp64 from
+ *                     ~1e7 points, bf16 separable boxes from 1.2e7), 0 never, 1 always; steps_per_launch = 4 asks for them too
  *   spans3            3D register-resident kernels (fp64 and bf16, four applications per launch): how a launch is cut along
  *                     z.  0 = equal chunks per tile, 1 = spans (the line of all (tile, plane) pairs in equal pieces, one per
  *                     resident workgroup; csrc/spans.h), 2 = team spans (the line over tile rows, a piece per team of a
