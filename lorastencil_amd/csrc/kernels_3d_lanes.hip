@@ -194,9 +194,15 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
     };
     load_plane(0, nxt[0]);
 
-    auto step = [&](const int p, auto phase_tag, auto edge_tag) {
+    auto step = [&](const int p, auto phase_tag, auto edge_tag, auto levels_tag) {
         constexpr int P = decltype(phase_tag)::value, P1 = (P + 1) % 3, P2 = (P + 2) % 3;
         constexpr bool EDGE = decltype(edge_tag)::value;
+        // NA < K: a copy of the step for a segment's first steps, where the upper levels have nothing to do yet.  Level
+        // index l (levels l -> l + 1) takes in plane k0 - K + p - l, which feeds planes ... - 1 .. + 1 of level l + 1; the
+        // segment needs that level's planes from k0 - (K - l - 1) on: the level has work from step 2 l.  Steps 0 .. 2 K - 3
+        // run min(K, p / 2 + 1) levels: 12 level-steps = 3 steps' worth of a segment's zc + 2 K + 1 (K = 4) -- 3 % of the
+        // 96-plane chunks of box3d1r 768^3, 4 % of a 64-plane slab.
+        constexpr int NA = decltype(levels_tag)::value;
         // Everything issued one step ago has had a whole step to complete: the loads of plane p, the stores of the output
         // plane before last.  The plane loads are plain loads on purpose: the compiler waits for them where they are first
         // used -- right here, and with stores outstanding beside them it waits for vmcnt(0), which is what this step wants
@@ -255,7 +261,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
             // row (rows 1 .. 3 of the lane's four, but for row 3's last tap); behind the barrier come row 0 and that tap.
             // A second barrier right before the publication keeps it behind the last step's reads.
 #pragma unroll
-            for (int l = 0; l < K; ++l) {
+            for (int l = 0; l < NA; ++l) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     acc[l][P][r][0] = fma(W.w[22], l == 0 ? v0[r][0] : acc[l - 1][P][r][0], acc[l][P][r][0]);
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(LORA_L3_ABLATE & 1)) asm volatile("s_barrier" ::: "memory");
 #pragma unroll
-            for (int l = 0; l < K; ++l) {
+            for (int l = 0; l < NA; ++l) {
                 const double(&in)[4][2] = l == 0 ? v0 : acc[l - 1][P];
                 *reinterpret_cast<d2 *>(&edge_rows[l][wv][0][2 * lane]) = (d2){in[0][0], in[0][1]};
                 *reinterpret_cast<d2 *>(&edge_rows[l][wv][1][2 * lane]) = (d2){in[3][0], in[3][1]};
@@ -298,20 +304,20 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
                 }
             };
 #pragma unroll
-            for (int l = 0; l + 1 < K; ++l) own_rows(l);
+            for (int l = 0; l + 1 < NA; ++l) own_rows(l);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!(LORA_L3_ABLATE & 1)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             d2 vu[K], vd[K];
 #pragma unroll
-            for (int l = 0; l < K; ++l) {
+            for (int l = 0; l < NA; ++l) {
                 vu[l] = *reinterpret_cast<const d2 *>(&edge_rows[l][up][1][2 * lane]);
                 vd[l] = *reinterpret_cast<const d2 *>(&edge_rows[l][dn][0][2 * lane]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            own_rows(K - 1);  // (while the neighbours' rows arrive)
+            own_rows(NA - 1);  // (while the neighbours' rows arrive)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int l = 0; l < ((LORA_L3_ABLATE & 64) ? 0 : K); ++l) {
+            for (int l = 0; l < ((LORA_L3_ABLATE & 64) ? 0 : NA); ++l) {
                 const double(&in)[4][2] = l == 0 ? v0 : acc[l - 1][P];
                 const double xl = lane_below(in[0][1]), xr = lane_above(in[0][0]);
                 double s0 = fma(W.w[10], vu[l].x, acc[l][P1][0][0]), s1 = fma(W.w[10], vu[l].y, acc[l][P1][0][1]);
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
             // form of its first and last row (the same multiply-adds on the same cells whoever does them): the neighbours'
             // rows then cost no x-pass of their own, and the wave's own x-pass runs ahead of the barrier.
 #pragma unroll
-            for (int l = 0; l < K; ++l) {
+            for (int l = 0; l < NA; ++l) {
                 const double(&in)[4][2] = l == 0 ? v0 : acc[l - 1][P];
                 double t0[6], t1[6];
 #pragma unroll
@@ -382,11 +388,29 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
     if (LORA_L3_ABLATE & 32) p1 = steps;
     const int t1 = min((p1 + 2) / 3, turns), t2 = min(max(p2 / 3, t1), turns);
     auto turn = [&](const int p, auto edge_tag) {
-        step(p, std::integral_constant<int, 0>{}, edge_tag);
-        step(p + 1, std::integral_constant<int, 1>{}, edge_tag);
-        step(p + 2, std::integral_constant<int, 2>{}, edge_tag);
+        step(p, std::integral_constant<int, 0>{}, edge_tag, std::integral_constant<int, K>{});
+        step(p + 1, std::integral_constant<int, 1>{}, edge_tag, std::integral_constant<int, K>{});
+        step(p + 2, std::integral_constant<int, 2>{}, edge_tag, std::integral_constant<int, K>{});
     };
     int t = 0;
+    if constexpr (!(LORA_L3_ABLATE & 128)) {
+        // the first turns of a segment with only the levels that have work (EDGE copies: forcing cells that need none
+        // changes nothing); a segment has at least 2 K + 2 steps
+        auto fill = [&](auto p_tag) {
+            constexpr int p = decltype(p_tag)::value;
+            step(p, std::integral_constant<int, p % 3>{}, std::true_type{}, std::integral_constant<int, (p / 2 + 1 < K ? p / 2 + 1 : K)>{});
+        };
+        fill(std::integral_constant<int, 0>{});
+        fill(std::integral_constant<int, 1>{});
+        fill(std::integral_constant<int, 2>{});
+        t = 1;
+        if constexpr (K > 2) {
+            fill(std::integral_constant<int, 3>{});
+            fill(std::integral_constant<int, 4>{});
+            fill(std::integral_constant<int, 5>{});
+            t = 2;
+        }
+    }
     for (; t < t1; ++t) turn(3 * t, std::true_type{});
     for (; t < t2; ++t) turn(3 * t, std::false_type{});
     for (; t < turns; ++t) turn(3 * t, std::true_type{});
