@@ -71,6 +71,10 @@ struct ArgsL3 {
     int z_begin2, z_end2;  // a second range of planes in the same launch (chunks only): the two end regions of a slab
     int zc;
     int tiles_x, tiles_y;
+#ifdef LORA_L3_STAMP
+    long long *stamps;  // probe builds: per workgroup {start, end} on the 100 MHz clock, {tile x | y << 16 | rim << 31, first plane}
+#endif
+    int slow_c, slow_zc;  // chunks, one round with slots to spare: the tiles of the first tile column and row get slow_c chunks of slow_zc planes (0: off)
     Spans sp;  // zc == 0: spans (spans.h)
     int team;  // zc == 0: 0 = a span per workgroup over all tiles; TX = a span per TEAM of the TX workgroups of a tile row
 };
@@ -128,14 +132,42 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
     } else {
         int chunk;
         const int c0 = (a.z_end - a.z_begin + a.zc - 1) / a.zc, c1 = (a.z_end2 - a.z_begin2 + a.zc - 1) / a.zc;
-        chunk_of(lin, c0 + c1, TX, TY, chunk, tx, ty);
-        const int zb = chunk < c0 ? a.z_begin : a.z_begin2, ze = chunk < c0 ? a.z_end : a.z_end2;
-        k0 = zb + (chunk < c0 ? chunk : chunk - c0) * a.zc;
-        zc = min(a.zc, ze - k0);
+        if (a.slow_c > 0) {
+            // A launch of ONE round with slots to spare: the full rim tiles -- first tile column and first tile row: EDGE
+            // steps on every lane's worth of memory traffic, 8 - 17 % longer than an inner tile's (tools/probes/
+            // lanes3_timeline.hip) -- are cut into one chunk more than the others, so that the launch no longer waits for them.
+            const int nslow = TX + TY - 1, na = nslow * a.slow_c;
+            if (lin < na) {
+                const int j = lin / a.slow_c;
+                chunk = lin - j * a.slow_c;
+                tx = j < TY ? 0 : j - TY + 1;
+                ty = j < TY ? j : 0;
+                k0 = a.z_begin + chunk * a.slow_zc;
+                zc = min(a.slow_zc, a.z_end - k0);
+            } else {
+                const int l2 = lin - na, i = l2 / c0;
+                chunk = l2 - i * c0;
+                ty = 1 + i / (TX - 1);
+                tx = 1 + i - (ty - 1) * (TX - 1);
+                k0 = a.z_begin + chunk * a.zc;
+                zc = min(a.zc, a.z_end - k0);
+            }
+        } else {
+            chunk_of(lin, c0 + c1, TX, TY, chunk, tx, ty);
+            const int zb = chunk < c0 ? a.z_begin : a.z_begin2, ze = chunk < c0 ? a.z_end : a.z_end2;
+            k0 = zb + (chunk < c0 ? chunk : chunk - c0) * a.zc;
+            zc = min(a.zc, ze - k0);
+        }
         more = false;
     }
     // (the segment before is done with the rows in LDS when its slowest wave is)
     if (!first) __builtin_amdgcn_s_barrier();
+#ifdef LORA_L3_STAMP
+    if (a.stamps && threadIdx.x == 0) {
+        a.stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[4 * blockIdx.x + 3] = k0;
+    }
+#endif
     const int X0 = tx * kOutW - 4, Y0 = ty * OH - K;  // interior coordinates of the tile's first column / row
     // this lane's cells: rows Y0 + 4 wv + r (r = 0 .. 3), columns X0 + 2 lane, + 1; padded: + 2 rows, + 4 columns, clamped
     // into the padded array (clamped cells only feed cells outside the interior, which EDGE forces, or nothing)
@@ -415,6 +447,12 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
     for (; t < t2; ++t) turn(3 * t, std::false_type{});
     for (; t < turns; ++t) turn(3 * t, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef LORA_L3_STAMP
+    if (a.stamps && threadIdx.x == 0) {
+        a.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        a.stamps[4 * blockIdx.x + 2] = (long long) tx | ((long long) ty << 16) | ((long long) xy_rim << 31);
+    }
+#endif
     }  // segments
 }
 
@@ -480,7 +518,23 @@ hipError_t launch_lanes_t(const Plan &p, const double *in, double *out, int begi
         if (nblocks == 0) a.zc = zc_model;  // (or a line that does not fit 31 bits of cost units)
     }
     if (a.zc > 0) nblocks = tiles * ((depth + a.zc - 1) / a.zc + (depth2 + a.zc - 1) / a.zc);
+    if (a.zc > 0 && depth2 == 0 && p.fused_z_chunk <= 0 && a.tiles_x >= 2 && a.tiles_y >= 2 && !(LORA_L3_ABLATE & 256)) {
+        // one round with slots to spare: one chunk more for the tiles of the first tile column and row (see the kernel)
+        const long c = (depth + a.zc - 1) / a.zc, nslow = a.tiles_x + a.tiles_y - 1;
+        const long slow_zc = (depth + c) / (c + 1);
+        if (nblocks <= slots && nblocks + nslow <= slots && slow_zc >= 2 * K) {
+            a.slow_c = (int) ((depth + slow_zc - 1) / slow_zc);
+            a.slow_zc = (int) slow_zc;
+            nblocks = nslow * a.slow_c + (tiles - nslow) * c;
+        }
+    }
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
+#ifdef LORA_L3_STAMP
+    extern long long *g_l3_stamps;
+    extern long g_l3_stamp_blocks;
+    a.stamps = g_l3_stamps;
+    g_l3_stamp_blocks = nblocks;
+#endif
     Taps27 w;
     for (int k = 0; k < 27; ++k) w.w[k] = p.w[k];
     if (TAPSET == TAPS3D_SEP)
