@@ -74,6 +74,7 @@ struct ArgsL3 {
 #ifdef LORA_L3_STAMP
     long long *stamps;  // probe builds: per workgroup {start, end} on the 100 MHz clock, {tile x | y << 16 | rim << 31, first plane}
 #endif
+    int deal;  // chunks, more workgroups' worth than slots: the launch is `slots` workgroups and chunk j goes to workgroup j mod slots (0: off)
     int slow_c, slow_zc;  // chunks, one round with slots to spare: the tiles of the first tile column and row get slow_c chunks of slow_zc planes (0: off)
     Spans sp;  // zc == 0: spans (spans.h)
     int team;  // zc == 0: 0 = a span per workgroup over all tiles; TX = a span per TEAM of the TX workgroups of a tile row
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
     // the end of the launch).
     unsigned v0 = 0, v1 = 0;
     if (a.zc == 0) span_range(a.sp, a.team ? lin / a.team : lin, v0, v1);
+    int job = lin;  // chunks dealt out (a.deal): this workgroup's next chunk
     for (bool more = true, first = true; more; first = false) {
     int tx, ty, k0, zc;
     if (a.zc == 0) {
@@ -153,12 +155,18 @@ __global__ __launch_bounds__(NW * 64, 2) void stencil3d_lanes_kernel(const ArgsL
                 zc = min(a.zc, a.z_end - k0);
             }
         } else {
-            chunk_of(lin, c0 + c1, TX, TY, chunk, tx, ty);
+            // (a.deal: the chunks of a launch of several rounds are DEALT to the resident workgroups, chunk j to workgroup
+            // j mod slots, instead of being dispatched one workgroup each as slots fall free.  Every workgroup then runs the
+            // same number of chunks and about the same number of rim chunks.  Dispatched one by one, the 1792 chunks of
+            // box3d1r 768^3 -- seven rounds exactly, rim chunks 259 us, inner ones 225 -- left some CUs with eight chunks and
+            // others with six: the last tenth of the launch ran on 96 of 256 CUs, profiles/r04_lanes3_timeline.txt.)
+            chunk_of(job, c0 + c1, TX, TY, chunk, tx, ty);
             const int zb = chunk < c0 ? a.z_begin : a.z_begin2, ze = chunk < c0 ? a.z_end : a.z_end2;
             k0 = zb + (chunk < c0 ? chunk : chunk - c0) * a.zc;
             zc = min(a.zc, ze - k0);
+            job += (int) gridDim.x;
         }
-        more = false;
+        more = a.deal > 0 && job < a.deal;
     }
     // (the segment before is done with the rows in LDS when its slowest wave is)
     if (!first) __builtin_amdgcn_s_barrier();
@@ -527,6 +535,11 @@ hipError_t launch_lanes_t(const Plan &p, const double *in, double *out, int begi
             a.slow_zc = (int) slow_zc;
             nblocks = nslow * a.slow_c + (tiles - nslow) * c;
         }
+    }
+    if (a.zc > 0 && a.slow_c == 0 && nblocks > slots && !(LORA_L3_ABLATE & 512)) {  // several rounds: deal the chunks out
+        if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
+        a.deal = (int) nblocks;
+        nblocks = slots;
     }
     if (nblocks > 0x7fffffffL) return hipErrorInvalidValue;
 #ifdef LORA_L3_STAMP

@@ -544,6 +544,40 @@ def test_3d_register_resident_kernel_equals_step_by_step(L, O, shape, dims):
                 assert rel_err(got, exp) < 1e-13, f"{shape} {dims} t={t} {cut}"
 
 
+@pytest.mark.parametrize("shape,dims", [("star3d1r", (200, 600, 760)), ("box3d1r", (200, 600, 760)), ("star3d1r", (512, 512, 512)),
+                                        ("box3d1r", (96, 250, 1000))])
+def test_3d_register_resident_kernel_launch_shapes_at_size(L, O, shape, dims):
+    """The ways a big launch of the fp64 register-resident kernel is laid out -- chunks DEALT to the resident workgroups when
+    there are more chunks than CUs (200 x 600 x 760: 175 tiles), one chunk more for the tiles of the first tile column and
+    row when a single round has CUs to spare (512^3) -- against single sweeps: runs of four and nine sweeps, whole
+    padded buffer, bit for bit on small integers (every cut of the launch must give the same bits too)."""
+    import torch
+
+    ps = L.padded_shape(shape, dims)
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    a = torch.randint(0, 4, ps, generator=gen, device="cuda").to(torch.float64)
+    w = O.effective_weights(shape)  # integer taps on small integers: exact while 36^t x 3 < 2^53
+
+    def run(t, opts):
+        plan = L.Plan(shape, dims).set_weights(w)
+        for k, v in opts.items():
+            plan.set_option(k, v)
+        b0, b1 = a.clone(), torch.zeros_like(a)
+        plan.run(b0, b1, t)
+        torch.cuda.synchronize()
+        return (b0, b1)[t % 2], plan.kernel_name
+
+    for t in (4, 9):
+        ref, _ = run(t, {"steps_per_launch": 1})
+        assert float(ref.abs().max()) < 2.0 ** 53
+        for opts in ({"steps_per_launch": 4}, {"steps_per_launch": 4, "spans3": 1}, {"steps_per_launch": 4, "fused_z_chunk": 24}):
+            got, kn = run(t, opts)
+            assert kn == "stencil3d_lanes_kernel"
+            assert torch.equal(got, ref), (shape, dims, t, opts)
+            del got
+        del ref
+
+
 @pytest.mark.parametrize("shape", ["star3d1r", "box3d1r"])
 def test_3d_register_resident_kernel_real_data_and_regions(L, O, shape):
     """Random real data and taps: four applications in one launch == four single sweeps bit for bit (star: same tap order;
