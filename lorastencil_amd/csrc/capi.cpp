@@ -917,6 +917,22 @@ int lora_plan_step2_region(lora_plan *plan, const void *d_in, void *d_out, int b
     if (p.ndim == 3 && p.lanes3_active) {  // the two-application tail of a four-application plan (also: odd innermost extents)
         if (int rc = lora::check_buffers(d_in, d_out)) return rc;
         if (d_in == d_out || begin < 0 || end > p.dims[0] || begin > end) return LORA_EINVAL;
+        // Two sweeps move the same bytes as four, and at that the plane-streaming kernel is the faster of the two (star3d1r
+        // 512^3: 475 against 551 us; box3d1r 768^3: 1651 against 1893; tools/tail_time.py) -- same taps in the same order,
+        // same bits.  Deep regions of even-extent fp64 grids take it; the rest (thin regions, odd extents, bf16) stays here.
+        if (p.dtype != LORA_BF16 && !p.generic && p.stream3 != 0 && end - begin >= 128) {
+            Plan q = p;
+            q.lanes3_active = 0;
+            q.stream3_active = 1;
+            q.steps_per_launch = 2;
+            const hipError_t e = lora::launch_3d_stream(q, 2, static_cast<const double *>(d_in), static_cast<double *>(d_out),
+                                                        static_cast<const double *>(d_in), 0, begin, end, static_cast<hipStream_t>(stream));
+            if (e != hipSuccess) {
+                lora::set_last_error("fused plane-streaming kernel launch (two-application tail)", e);
+                return LORA_EHIP;
+            }
+            return LORA_OK;
+        }
         const hipError_t e = p.dtype == LORA_BF16
                                  ? lora::launch_3d_bf16_lanes(p, 2, d_in, d_out, begin, end, static_cast<hipStream_t>(stream))
                                  : lora::launch_3d_lanes(p, 2, static_cast<const double *>(d_in), static_cast<double *>(d_out), begin,

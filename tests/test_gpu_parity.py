@@ -549,7 +549,7 @@ def test_3d_register_resident_kernel_equals_step_by_step(L, O, shape, dims):
 def test_3d_register_resident_kernel_launch_shapes_at_size(L, O, shape, dims):
     """The ways a big launch of the fp64 register-resident kernel is laid out -- chunks DEALT to the resident workgroups when
     there are more chunks than CUs (200 x 600 x 760: 175 tiles), one chunk more for the tiles of the first tile column and
-    row when a single round has CUs to spare (512^3) -- against single sweeps: runs of four and nine sweeps, whole
+    row when a single round has CUs to spare (512^3) -- against single sweeps: runs of four, six and nine sweeps, whole
     padded buffer, bit for bit on small integers (every cut of the launch must give the same bits too)."""
     import torch
 
@@ -567,7 +567,7 @@ def test_3d_register_resident_kernel_launch_shapes_at_size(L, O, shape, dims):
         torch.cuda.synchronize()
         return (b0, b1)[t % 2], plan.kernel_name
 
-    for t in (4, 9):
+    for t in (4, 6, 9):  # (6 = four + a two-application tail: the plane-streaming kernel on regions of 128 planes and more)
         ref, _ = run(t, {"steps_per_launch": 1})
         assert float(ref.abs().max()) < 2.0 ** 53
         for opts in ({"steps_per_launch": 4}, {"steps_per_launch": 4, "spans3": 1}, {"steps_per_launch": 4, "fused_z_chunk": 24}):
