@@ -39,8 +39,10 @@
 //   * Halo semantics: cells of an intermediate level outside the interior are 0 at odd levels and the source
 //     buffer's own halo value at even ones (level 2 of four).  Rim tiles, and every tile in the steps whose planes lie
 //     outside the z range, run an EDGE copy of the step that forces them with a bit-field insert per pair; the level-2
-//     values come from the input array (while fused launches run every buffer carries buffer 0's halo) by a buffer load
-//     in which only the lanes holding such a cell make a memory request, issued at the start of the step.
+//     values are the input's own values three planes back (while fused launches run every buffer carries buffer 0's halo):
+//     the lane's dwords of a plane that is still in the input ring.
+//   * A segment's first 3 (K - 1) and last K - 1 steps run a FILL copy of the step that skips the levels with no work yet /
+//     any more; the launch is cut along z into chunks, spans or team spans (spans.h).
 //
 // Taps: exactly separable 27-point boxes (TAPS3D_SEP: every box3d1r the reference's API can express, 3d/gpu_box.cu:158-164).
 #include <hip/hip_runtime.h>

@@ -11,8 +11,11 @@
 //
 // What it buys is measured, not assumed (tools/spans_sweep.py, profiles/r04_spans_*): fewer cycles everywhere, but
 // neighbouring tiles are no longer at the same depth at the same time, so the rows they share -- and the 128-byte lines
-// their misaligned row pieces straddle -- are fetched from HBM twice.  Plan option spans3 (-1 by the kernel's own rule,
-// 0 chunks, 1 spans).
+// their misaligned row pieces straddle -- are fetched from HBM twice.  TEAM spans (the line over tile rows, a piece per
+// team of a row's workgroups) keep the neighbours in x together.  Plan option spans3: -1 by the kernels' rules (spans_pay,
+// teams_pay), 0 chunks, 1 spans, 2 team spans.  Chunked launches have two layouts of their own in kernels_3d_lanes.hip:
+// chunks dealt to resident workgroups when there are more chunks than CUs, and one chunk more for the slow rim tiles when a
+// single round has CUs to spare.
 #pragma once
 
 #include <algorithm>
