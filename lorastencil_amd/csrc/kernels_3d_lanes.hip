@@ -15,8 +15,9 @@
 //     two edge rows each wave publishes per level (2 ds_write_b128 + 2 ds_read_b128 per wave and level instead of 4 + 18);
 //     z is streamed: per level and point two partial sums live between steps (the plane above has its dz = 0 tap, the
 //     plane at hand its dz = 0 and dz = 1 taps), the third is completed in the step and becomes the next level's input.
-//   * So K = 4 fits: 4 x 32 partial-sum registers + planes in flight = 236 VGPRs, two waves per SIMD, 64 KB of the CU's
-//     160 KB of LDS (registers, not LDS, are what holds it to one 512-thread workgroup per CU).
+//   * So K = 4 fits: 4 x 32 partial-sum registers + planes in flight = 252 VGPRs, two waves per SIMD; LDS: 64 KB of edge
+//     rows + the 96 KB delay line of the EDGE steps = the CU's whole 160 KB (K = 2: 32 KB).  Registers AND LDS hold it to
+//     one 512-thread workgroup per CU.
 //     The grid is read once and written once per FOUR sweeps (4 B per point and sweep compulsory).
 //   * Per accumulator the taps arrive in the oracle's order (dz, then dy, then dx): bit-identical to four single sweeps
 //     (and to the other fused 3D kernels), also for the separable box (x-pass, y-pass, z-scatter as in planes_3d.h).
