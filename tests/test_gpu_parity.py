@@ -578,6 +578,40 @@ def test_3d_register_resident_kernel_launch_shapes_at_size(L, O, shape, dims):
         del ref
 
 
+@pytest.mark.parametrize("shape,dtype", [("box3d1r", "f64"), ("star3d1r", "f64"), ("box3d1r", "bf16")])
+def test_3d_register_resident_kernel_is_deterministic_under_repetition(L, O, shape, dtype):
+    """Many repetitions of one fused run give the same bits every time, under every cut of the launch.  (Round 4: the fp64
+    separable path's first steps run one level alone and had no barrier between a wave's rewrite of its edge rows and its
+    neighbours' reads of the step before -- errors of 1e-3 in one run of ~200, never twice the same; this test is the watch
+    on that class of bug: workgroups that run several segments are the ones that start most often.)"""
+    import torch
+
+    dims = (150, 110, 376)
+    rng = np.random.default_rng(5)
+    w = O.effective_weights(shape)
+    w = w / w.sum()
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float64
+    a = torch.from_numpy(rng.standard_normal(O.padded_shape(shape, dims))).to(tdt).cuda()
+    it = torch.int16 if dtype == "bf16" else torch.int64
+    for cut in (2, 1, -1):
+        plan = L.Plan(shape, dims, dtype=dtype).set_weights(w).set_option("steps_per_launch", 4).set_option("spans3", cut)
+        first = None
+        for rep in range(40):
+            b0, b1 = a.clone(), torch.zeros_like(a)
+            plan.run(b0, b1, 8)
+            torch.cuda.synchronize()
+            if first is None:
+                first = b0.clone()
+                single = L.Plan(shape, dims, dtype=dtype).set_weights(w).set_option("steps_per_launch", 1)
+                c0, c1 = a.clone(), torch.zeros_like(a)
+                single.run(c0, c1, 8)
+                torch.cuda.synchronize()
+                assert rel_err(b0.double().cpu().numpy(), c0.double().cpu().numpy()) < (1e-13 if dtype == "f64" else 1e-30) or \
+                    torch.equal(b0.view(it), c0.view(it)), (shape, dtype, cut)
+            else:
+                assert torch.equal(b0.view(it), first.view(it)), (shape, dtype, cut, rep)
+
+
 @pytest.mark.parametrize("shape", ["star3d1r", "box3d1r"])
 def test_3d_register_resident_kernel_real_data_and_regions(L, O, shape):
     """Random real data and taps: four applications in one launch == four single sweeps bit for bit (star: same tap order;
