@@ -1489,6 +1489,21 @@ def test_randomised_parity_against_the_oracle(L, O):
     assert kinds.get("exact", 0) > 20 and kinds.get("bits", 0) > 10 and kinds.get("rel", 0) > 50
 
 
+def test_randomised_sweep_of_the_round_4_launch_paths(L, O):
+    """tools/fuzz_r04.py for twenty seconds with a fixed seed (its case sequence is the same every time): the
+    register-resident 3D kernels under every cut of a launch, fp64 and bf16, two ranges in one launch, the periodic option on
+    a ghost-extended grid, full-rank 49-tap tables -- each against single sweeps of the same plan family.  (The sweep that
+    found the missing barrier of the fp64 separable path's one-level steps.)"""
+    import subprocess
+    import sys
+
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_r04.py"), "--seconds", "20", "--seed", "20261005"],
+                       capture_output=True, text=True, timeout=300)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0 and "cases agree" in r.stdout, tail
+    assert "MISMATCH" not in r.stdout and "ERROR" not in r.stdout, tail
+
+
 # ---------------------------------------------------------------------------------------------------------
 # BASELINE.json full sizes: size-independent properties + sampled windows against the oracle
 # ---------------------------------------------------------------------------------------------------------
