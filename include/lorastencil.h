@@ -264,7 +264,7 @@ int lora_plan_stepn_region(lora_plan *plan, int napps, const void *d_in, void *d
 int lora_plan_stepn_region2(lora_plan *plan, int napps, const void *d_in, void *d_out, int begin0, int end0, int begin1, int end1,
                             void *stream);
 /* Test support, no device needed: replays on the host the decode the register-resident 3D kernels run for a launch cut into
- * spans (team = 0) or team spans (team = 1; csrc/spans.h) over tiles_x x tiles_y tiles and `depth` planes on `slots`
+ * spans (team = 0), team spans (team = 1) or team spans with the rim columns cut finer (team = 2; csrc/spans.h) over tiles_x x tiles_y tiles and `depth` planes on `slots`
  * resident workgroups with S steps of start per segment.  cover[(ty * tiles_x + tx) * depth + z] is incremented once per
  * segment that sweeps the pair (the caller zeroes it): every entry must come out 1. */
 int lora_debug_span_cover(int tiles_x, int tiles_y, int depth, int S, int slots, int team, int *cover, int *workgroups, int *max_steps);

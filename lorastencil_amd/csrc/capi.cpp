@@ -1238,6 +1238,51 @@ int lora_debug_span_cover(int tiles_x, int tiles_y, int depth, int S, int slots,
     if (tiles_x < 1 || tiles_y < 1 || depth < 1 || S < 1 || slots < 1 || !cover) return LORA_EINVAL;
     lora::Spans sp{};
     long wgs;
+    if (team == 2) {
+        // team spans as the bf16 kernel launches them: column lines with weighted rim rows, the rim columns cut finer
+        if (tiles_x > slots) return LORA_EUNSUPPORTED;
+        lora::Spans sp2{};
+        long ni, nr;
+        lora::team_pieces(tiles_x, slots, true, &ni, &nr);
+        const bool weigh = tiles_x >= 3;
+        const long ti = ni > 0 ? lora::spans_setup_column(sp, tiles_y, depth, S, ni, weigh ? 19 : 1, weigh ? 18 : 1) : 0;
+        const long tr = nr > 0 ? lora::spans_setup_column(sp2, tiles_y, depth, S, nr, 1, 1) : 0;
+        if (ti <= 0 || tr < ti) return LORA_EUNSUPPORTED;
+        const long team_nr = tiles_x >= 3 ? tr : ti;
+        wgs = tiles_x >= 3 ? ti * (tiles_x - 2) + 2 * tr : ti * tiles_x;
+        int busiest2 = 0;
+        for (long lin = 0; lin < wgs; ++lin) {
+            long j;
+            int col;
+            if (lin < (long) tiles_x * ti) {
+                j = lin / tiles_x;
+                col = (int) (lin - j * tiles_x);
+            } else {
+                const long r = lin - (long) tiles_x * ti;
+                j = ti + (r >> 1);
+                col = (r & 1) ? tiles_x - 1 : 0;
+            }
+            const bool rim_col = team_nr != ti && (col == 0 || col == tiles_x - 1);
+            const lora::Spans &t = rim_col ? sp2 : sp;
+            unsigned v0, v1;
+            lora::span_range(t, (int) j, v0, v1);
+            int steps = 0;
+            for (bool more = true; more;) {
+                int t0, ty, z0, zc;
+                const bool any = lora::span_next(t, S, v0, v1, 1, tiles_y, t0, ty, z0, zc);
+                ty = lora::column_line_row(ty, tiles_y);
+                more = v0 < v1;
+                if (!any) continue;
+                if (ty < 0 || ty >= tiles_y || z0 < 0 || z0 + zc > depth) return LORA_EHIP;  // (out of range: a bug)
+                for (int z = z0; z < z0 + zc; ++z) cover[((long) ty * tiles_x + col) * depth + z] += 1;
+                steps += S + zc;
+            }
+            busiest2 = std::max(busiest2, steps);
+        }
+        if (workgroups) *workgroups = (int) wgs;
+        if (max_steps) *max_steps = busiest2;
+        return LORA_OK;
+    }
     if (team) {
         if (tiles_x > slots) return LORA_EUNSUPPORTED;
         wgs = lora::spans_setup(sp, 1, tiles_y, depth, S, slots / tiles_x, 1, 1) * tiles_x;

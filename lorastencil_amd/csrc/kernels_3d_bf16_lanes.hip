@@ -54,7 +54,7 @@
 #include "spans.h"
 
 // Timing experiments for tools/probes/bf16_lanes_ablate.hip (results are WRONG with bits 1 .. 16 set): 1 no barriers, 2 no
-// stores, 4 no plane loads after the first, 8 no EDGE steps, 16 only EDGE steps, 256 no FILL copy of the first / last steps
+// stores, 4 no plane loads after the first, 8 no EDGE steps, 16 only EDGE steps, 256 no FILL copy of the first / last steps, 512 team spans with equal pieces in every tile column
 // (right results); 32 = the taps as scalar operands (right
 // results, the form the first version of this kernel had: an fp32 instruction with a scalar operand issues at half rate)
 #ifndef LORA_BL_ABLATE
@@ -100,8 +100,15 @@ struct ArgsBL {
     int tiles_x, tiles_y;
     Spans sp;  // zc == 0: spans (spans.h)
     int team;  // zc == 0: 0 = a span per workgroup over all tiles; TX = a span per TEAM of the TX workgroups of a tile row
+    // team spans: the first / last tile COLUMN (rim tiles: EDGE steps, 5 % longer each) is cut into team_nr pieces (Spans sp2),
+    // the columns between into team_ni (Spans sp); team_nr == team_ni: whole teams in lockstep
+    int team_ni, team_nr;
+    Spans sp2;
 #if LORA_BL_STAMP
     long long *stamps;  // [workgroup][wave][2]: cycles of the stamped phase, steps
+#endif
+#ifdef LORA_BL_TIMELINE
+    long long *timeline;  // probe builds: per workgroup {first start, last end} on the 100 MHz clock, steps run, segments | rim << 32
 #endif
 };
 struct TapsSep {
@@ -300,7 +307,28 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
     // Spans (a.zc == 0, spans.h): the workgroup owns a range of the line of all (tile, plane) pairs and runs one SEGMENT per
     // tile the range touches; chunks (option fused_z_chunk / spans3 = 0): one segment, chunk `lin / tiles` of its tile.
     unsigned v0 = 0, v1 = 0;
-    if (a.zc == 0) span_range(a.sp, a.team ? lin / a.team : lin, v0, v1);
+    int team_col = 0;  // team spans: this workgroup's tile column
+    if (a.zc == 0 && a.team) {
+        // workgroups 0 .. TX team_ni - 1: piece lin / TX of column lin mod TX (x-neighbours side by side: one L2); the rest:
+        // the extra pieces of the two rim columns
+        int j;
+        if (lin < a.team * a.team_ni) {
+            j = lin / a.team;
+            team_col = lin - j * a.team;
+        } else {
+            const int r = lin - a.team * a.team_ni;
+            j = a.team_ni + (r >> 1);
+            team_col = (r & 1) ? a.team - 1 : 0;
+        }
+        const bool rim_col = a.team_nr != a.team_ni && (team_col == 0 || team_col == a.team - 1);
+        if (rim_col)
+            span_range(a.sp2, j, v0, v1);
+        else
+            span_range(a.sp, j, v0, v1);
+    } else if (a.zc == 0) {
+        span_range(a.sp, lin, v0, v1);
+    }
+    const Spans &tsp = (a.team && a.team_nr != a.team_ni && (team_col == 0 || team_col == a.team - 1)) ? a.sp2 : a.sp;
     for (bool more = true, first = true; more; first = false) {
     int tx, ty, k0, zc;
     if (a.zc == 0) {
@@ -308,8 +336,9 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
         bool any;
         if (a.team) {  // the line runs over tile ROWS; this workgroup is column lin mod TX of its team's row
             int t0;
-            any = span_next(a.sp, 3 * K - 1, v0, v1, 1, TY, t0, ty, z0, zc);
-            tx = lin - (lin / a.team) * a.team;
+            any = span_next(tsp, 3 * K - 1, v0, v1, 1, TY, t0, ty, z0, zc);
+            ty = column_line_row(ty, TY);
+            tx = team_col;
         } else {
             any = span_next(a.sp, 3 * K - 1, v0, v1, TX, TY, tx, ty, z0, zc);
         }
@@ -327,6 +356,13 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
     }
     // (the segment before is done with the rows in LDS when its slowest wave is)
     if (!first) __builtin_amdgcn_s_barrier();
+#ifdef LORA_BL_TIMELINE
+    if (a.timeline && threadIdx.x == 0) {
+        if (a.timeline[4 * blockIdx.x + 0] == 0) a.timeline[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
+        a.timeline[4 * blockIdx.x + 2] += zc + 3 * K - 1;
+        a.timeline[4 * blockIdx.x + 3] += 1;
+    }
+#endif
     const int X0 = tx * kOutW - 4, Y0 = ty * OH - K;  // interior coordinates of the tile's first column / row
     // this lane's cells: rows Y0 + R wv + r (r = 0 .. R - 1), columns X0 + 2 lane, + 1; padded: + 2 rows, + 4 columns,
     // clamped into the padded array (clamped cells only feed cells outside the interior, which EDGE forces, or nothing)
@@ -673,6 +709,9 @@ __global__ __launch_bounds__(NW * 64, 4) void stencil3d_bf16_lanes_kernel(const 
     for (; t < turns; ++t) turn(2 * t, std::true_type{}, std::true_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the DMA of a plane nobody reads: it must not land in a dead workgroup's LDS,
                                                       //  nor in the ring after the first plane of the next segment)
+#ifdef LORA_BL_TIMELINE
+    if (a.timeline && threadIdx.x == 0) a.timeline[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 #if LORA_BL_STAMP
     if (lane == 0) {  // (of the workgroup's last segment)
         a.stamps[((long) blockIdx.x * NW + wv) * 2] = stamp_sum;
@@ -738,9 +777,22 @@ hipError_t launch_t(const Plan &p, const void *in, void *out, int begin, int end
         if (teams && a.tiles_x <= slots) {
             // TEAM spans: the line runs over tile rows and is cut into one piece per team of tiles_x workgroups, one per
             // tile of the row -- x-neighbours stay at the same depth (and, dealt out contiguously, in the same XCD's L2)
-            const long nteams = spans_setup(a.sp, 1, a.tiles_y, depth, S, slots / a.tiles_x, 1, 1);
-            a.team = a.tiles_x;
-            nblocks = nteams * a.tiles_x;
+            // The rim columns' tiles run EDGE steps, ~5 % longer each (tools/probes/bf16_lanes_timeline.hip: 2.47 against 2.34
+            // us per step; with equal pieces the launch ended with the rim columns' workgroups at 775 us, the others at
+            // 734).  So the rim columns are cut into more, shorter pieces than the columns between -- 38 and 36 at 768^3, which
+            // also uses all 256 CUs instead of 252.  The columns between stay in lockstep with one another.
+            long ni, nr;
+            team_pieces(a.tiles_x, slots, !(LORA_BL_ABLATE & 512), &ni, &nr);
+            // (and within a column between them the first and last tile ROW are rim tiles too: their planes weigh 19 : 18)
+            const bool weigh = a.tiles_x >= 3 && !(LORA_BL_ABLATE & 512);
+            const long ti = ni > 0 ? spans_setup_column(a.sp, a.tiles_y, depth, S, ni, weigh ? 19 : 1, weigh ? 18 : 1) : 0;
+            const long tr = nr > 0 ? spans_setup_column(a.sp2, a.tiles_y, depth, S, nr, 1, 1) : 0;
+            if (ti > 0 && tr >= ti) {
+                a.team = a.tiles_x;
+                a.team_ni = (int) ti;
+                a.team_nr = (int) (a.tiles_x >= 3 ? tr : ti);
+                nblocks = a.tiles_x >= 3 ? ti * (a.tiles_x - 2) + 2 * tr : ti * a.tiles_x;
+            }
         } else if (spans) {
             nblocks = spans_setup(a.sp, a.tiles_x, a.tiles_y, depth, S, slots, 10, 9);
         }
@@ -759,6 +811,12 @@ hipError_t launch_t(const Plan &p, const void *in, void *out, int begin, int end
     extern long g_bl_stamp_blocks;
     a.stamps = g_bl_stamps;
     g_bl_stamp_blocks = nblocks;
+#endif
+#ifdef LORA_BL_TIMELINE
+    extern long long *g_bl_timeline;
+    extern long g_bl_timeline_blocks;
+    a.timeline = g_bl_timeline;
+    g_bl_timeline_blocks = nblocks;
 #endif
     hipLaunchKernelGGL(kernel, dim3((unsigned) nblocks), dim3(NW * 64), 0, s, a, w);
     return hipGetLastError();

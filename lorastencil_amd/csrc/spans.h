@@ -47,6 +47,33 @@ inline long spans_setup(Spans &sp, int tiles_x, int tiles_y, long depth, int S, 
     return wgs;
 }
 
+// The line of ONE tile column (team spans): tiles_y tiles, the first and last of them (rim rows: EDGE steps) at weight wrim and
+// FIRST on the line, the others at win.  Tile t of this line is row column_line_row(t, tiles_y).
+inline long spans_setup_column(Spans &sp, int tiles_y, long depth, int S, long slots, int wrim, int win) {
+    const long nrim = tiles_y >= 3 ? 2 : tiles_y;
+    sp.vt = (int) (depth + S);
+    sp.wrim = wrim;
+    sp.win = win;
+    sp.nrim = (int) nrim;
+    const long units = (depth + S) * (nrim * wrim + (tiles_y - nrim) * win);
+    if (units >= (1L << 31)) return 0;
+    const long wgs = std::max(1L, std::min(slots, units / ((long) S * win)));
+    sp.q = (int) (units / wgs);
+    sp.r = (int) (units % wgs);
+    return wgs;
+}
+
+// Team spans with the rim columns cut finer: how many pieces a tile column between the rim columns gets (ni) and how many a
+// rim column (nr >= ni), so that (tiles_x - 2) ni + 2 nr <= slots and nr / ni is about what a rim tile's steps cost more
+// (EDGE steps: ~5.5 %).  768^3 bf16 (7 columns, 256 CUs): 36 and 38.
+inline void team_pieces(int tiles_x, long slots, bool finer_rims, long *ni, long *nr) {
+    *ni = *nr = slots / tiles_x;
+    if (tiles_x >= 3 && finer_rims) {
+        *ni = (long) ((double) slots / ((double) (tiles_x - 2) + 2.0 * 1.055));
+        *nr = *ni > 0 ? std::min((slots - (tiles_x - 2) * *ni) / 2, (long) ((double) *ni * 1.07) + 1) : 0;
+    }
+}
+
 // Equal chunks per tile: the chunk length by a model of rounds of workgroups.  A chunk runs S steps beyond its own planes,
 // so chunks should be long; a round of workgroups (one per slot) takes its steps whatever its kernels do, and a LAST,
 // partly filled round is cheaper than a full one only down to about two thirds of it.  Fitted to a sweep of chunk lengths
@@ -154,6 +181,9 @@ LORA_SPANS_FN void chunk_of(int lin, int chunks, int TX, int TY, int &chunk, int
         rim_first_tile(rim + l2 - chunk * inner, TX, TY, tx, ty);
     }
 }
+
+// tile t of a tile column's line (spans_setup_column) -> tile row: the two rim rows first
+LORA_SPANS_FN int column_line_row(int t, int TY) { return TY < 3 ? t : (t == 0 ? 0 : (t == 1 ? TY - 1 : t - 1)); }
 
 // this workgroup's range [v0, v1) of the line
 LORA_SPANS_FN void span_range(const Spans &sp, int lin, unsigned &v0, unsigned &v1) {

@@ -305,7 +305,7 @@ def test_slab_schedule_is_the_same_on_every_rank(L, shape, dims, world):
     assert len(seen) == 1, seen
 
 
-@pytest.mark.parametrize("team", [0, 1])
+@pytest.mark.parametrize("team", [0, 1, 2])
 def test_spans_cover_every_tile_plane_exactly_once(L, team):
     """csrc/spans.h: a launch of the register-resident 3D kernels cut into spans / team spans.  The decode the kernels run
     is replayed on the host (lora_debug_span_cover): whatever the tile grid, depth, start length and number of resident
@@ -330,6 +330,9 @@ def test_spans_cover_every_tile_plane_exactly_once(L, team):
         counts = np.frombuffer(cover, dtype=np.int32)
         assert counts.min() == 1 and counts.max() == 1, (tx, ty, depth, S, slots, team, int(counts.min()), int(counts.max()))
         assert 1 <= wgs.value <= slots
+        if team == 2:  # (pieces per column differ: the rim columns' are shorter; the bound is on a column between them)
+            assert busiest.value <= 1.4 * ty * (depth + S) / max(1, (slots - 2) // max(tx, 1)) + 2 * S + 2 or tx < 3
+            continue
         groups = wgs.value // tx if team else wgs.value  # independent pieces of the line
         lines = ty if team else tx * ty
         even = lines * (depth + S) / groups
