@@ -321,13 +321,7 @@ def main():
         del dst_c
 
     reset()
-    # (the warm-up is untimed; its duration is only kept as this run's own yardstick for the throttle guard below)
-    w_ev0, w_ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    w_ev0.record()
     run(W)
-    w_ev1.record()
-    torch.cuda.synchronize()
-    warm_ms_per_sweep = w_ev0.elapsed_time(w_ev1) / W if W > 0 else None
     reset()  # keep the value range of the timed steps independent of the warm-up length
     # Launch-bound grids (<= 64 MB padded, >= 16 sweeps: the 1D configuration) run as the product runs them by default:
     # lora_plan_run captures its launches into a hipGraph on first use and replays it.  The capture is set-up work, done
@@ -371,10 +365,23 @@ def main():
     elapsed, ev_ms, prof = timed_region()
     # Throttle guard.  Twice in some fifty runs of this round a whole timed region ran FOUR times slower than every run
     # around it on the same code (83 ms instead of 21 for the 100 sweeps; the copy-bandwidth reference measured a moment
-    # earlier in the same process was normal): the box, not the kernels.  If the timed sweeps run more than 2.5 x slower
-    # than this run's own cold warm-up sweeps did, the region is timed ONCE more and both figures are reported.
+    # earlier in the same process was normal): the box, not the kernels.  The yardstick is this run's own: ONE more fused
+    # launch right behind the timed region (untimed for the metric).  If the timed sweeps ran more than twice as slow per
+    # sweep as that launch, the region is timed ONCE more and both figures are reported.
     retimed = None
-    slow = bool(not graph_replay and warm_ms_per_sweep and elapsed * 1e3 / K > 2.5 * warm_ms_per_sweep)
+    probe_ms_per_sweep = None
+    if not graph_replay:
+        n_probe = max(1, int(plan.get_option("steps_per_launch")))
+        n_probe += n_probe & 1  # (an even count: the buffers' halo state as at the start of a run)
+        reset()
+        p_ev0, p_ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        barrier()
+        p_ev0.record()
+        run(n_probe)
+        p_ev1.record()
+        barrier()
+        probe_ms_per_sweep = p_ev0.elapsed_time(p_ev1) / n_probe
+    slow = bool(probe_ms_per_sweep and elapsed * 1e3 / K > 2.0 * probe_ms_per_sweep)
     if world > 1:
         f = torch.tensor([1.0 if slow else 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(f, op=dist.ReduceOp.MAX)
@@ -383,8 +390,8 @@ def main():
         first_ms = elapsed * 1e3
         reset()
         elapsed, ev_ms, prof = timed_region()
-        retimed = {"first_region_ms": round(first_ms, 3), "warmup_ms_per_sweep": round(warm_ms_per_sweep, 4),
-                   "reason": "the first timed region ran > 2.5 x slower per sweep than this run's cold warm-up: timed once more"}
+        retimed = {"first_region_ms": round(first_ms, 3), "probe_ms_per_sweep": round(probe_ms_per_sweep, 4),
+                   "reason": "the first timed region ran > 2 x slower per sweep than one more launch right behind it: timed once more"}
     if graph_replay:
         reset()
         torch.cuda.synchronize()
@@ -560,6 +567,7 @@ def main():
                 "timed_region_ms": round(elapsed * 1e3, 2),
                 "clock_ramp_note": ("timed region < 50 ms: clocks still ramping" if elapsed < 0.05 else None),
                 "retimed": retimed,
+                "probe_ms_per_sweep": (round(probe_ms_per_sweep, 4) if probe_ms_per_sweep else None),
                 "launch_us": round(launch_s * 1e6, 2),
                 "launches": launches,
                 "bytes_per_launch": round(bytes_per_launch),
