@@ -286,6 +286,10 @@ int lora_copy_block_f64(void *d_dst, long dst_ld, const void *d_src, long src_ld
  * its own (one more padded array, allocated on first need, freed with the plan; option "scratch" = 0
  * trades it for a shorter launch schedule instead). */
 int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream);
+/* Allocates now what lora_plan_run(plan, ..., times, ...) would allocate on first need (the scratch grid of a schedule with
+ * an odd number of fused launches, the extended grid of a periodic run), so that a timed or latency-sensitive first run
+ * does not pay for it.  Optional and idempotent. */
+int lora_plan_prepare_run(lora_plan *plan, int times);
 /* lora_plan_run with HIP events recorded on `stream` around its two kinds of launches -- the fused multi-application
  * launches and the single-sweep tail -- so that a caller can quote the average duration of the dominant kernel over
  * the very region it timed (bench.py's roofline).  Launches directly (no hipGraph) and BLOCKS until the run has

@@ -185,6 +185,7 @@ SIGNATURES = {
     "lora_plan_step2_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lora_plan_stepk_region": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
     "lora_plan_stepn_region": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, _vp]),
+    "lora_plan_prepare_run": (ctypes.c_int, [_vp, ctypes.c_int]),
     "lora_plan_stepn_region2": (ctypes.c_int, [_vp, ctypes.c_int, _vp, _vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "lora_debug_span_cover": (ctypes.c_int, [ctypes.c_int] * 6 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "lora_plan_run": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_int, _vp]),

@@ -1664,6 +1664,22 @@ struct RunDepth1D {
     ~RunDepth1D() { p.steps_per_launch = saved; }
 };
 
+// Everything lora_plan_run(times) would allocate on first need, now: the scratch grid of a schedule with an odd number of
+// fused launches (a hipMalloc + hipMemset of one more padded grid -- usually a millisecond or two, but on a fresh device
+// it has taken 60 ms, INSIDE whatever region the caller was timing: the "four times slower" runs of DESIGN section 7), the
+// extended grid's plan and buffers of a periodic run.  Idempotent; lora_plan_run works without it.
+int lora_plan_prepare_run(lora_plan *plan, int times) {
+    if (!plan || times < 0) return LORA_EINVAL;
+    Plan &p = plan->p;
+    RunDepth1D depth(p, times);
+    if (p.boundary == LORA_BC_PERIODIC) {
+        if (times >= 2) (void) torus_prepare(plan);
+        return LORA_OK;
+    }
+    if (run_can_fuse(p) && !run_is_natural3(p)) (void) fused_schedule(plan, times, true);
+    return LORA_OK;
+}
+
 int lora_plan_run(lora_plan *plan, void *d_buf0, void *d_buf1, int times, void *stream) {
     if (!plan || times < 0) return LORA_EINVAL;
     Plan &p = plan->p;

@@ -401,6 +401,11 @@ class Plan:
                                                 ctypes.byref(prof)), "lora_plan_run_profiled")
         return prof
 
+    def prepare_run(self, times: int):
+        """Allocate now what ``run(..., times)`` would allocate on first need (scratch grid, extended periodic grid)."""
+        check(_lib.lib().lora_plan_prepare_run(self._h, int(times)), "lora_plan_prepare_run")
+        return self
+
     def run(self, d_buf0, d_buf1, times: int, stream=None):
         """`times` sweeps ping-ponging from d_buf0; the result is in buffer [times % 2]."""
         check(_lib.lib().lora_plan_run(self._h, _ptr(d_buf0), _ptr(d_buf1), int(times), _stream(stream)),
