@@ -320,14 +320,15 @@ def main():
         copy_gbs = 2.0 * src0.numel() * esize * 5 / (c0.elapsed_time(c1) / 1e3) / 1e9
         del dst_c
 
+    if world == 1:
+        # set-up, not sweeps: what the K-sweep run allocates on first need (the scratch grid of an odd number of fused
+        # launches: a hipMalloc + hipMemset of one more grid, which on a fresh device has taken 60 ms) exists before the
+        # warm-up, so that nothing but the reset of the buffers lies between the warm-up and the timed sweeps
+        plan.prepare_run(K)
+        torch.cuda.synchronize()
     reset()
     run(W)
     reset()  # keep the value range of the timed steps independent of the warm-up length
-    if world == 1:
-        # set-up, not sweeps: what the K-sweep run allocates on first need (the scratch grid of an odd number of fused
-        # launches: a hipMalloc + hipMemset of one more grid, which on a fresh device has taken 60 ms) exists before timing
-        plan.prepare_run(K)
-        torch.cuda.synchronize()
     # Launch-bound grids (<= 64 MB padded, >= 16 sweeps: the 1D configuration) run as the product runs them by default:
     # lora_plan_run captures its launches into a hipGraph on first use and replays it.  The capture is set-up work, done
     # once before the timed region by an untimed run of the same K sweeps on a side stream (graphs need a real stream);
